@@ -1,0 +1,102 @@
+/* clray_hip.h - C ABI of libclray_hip.so, the MI355X (gfx950) back end of the clray path tracer.
+ *
+ * This is the drop-in boundary for the reference's device seam, i.e. the methods of
+ * `Accelerator` (/root/reference/accelerator.py) that `Renderer` (/root/reference/renderer.py)
+ * calls, plus the per-pass / per-bounce launch schedule of `Renderer.render_sample`, which this
+ * library runs as ONE kernel launch for a whole batch of sample passes.
+ *
+ * Conventions: plain C, no C++ or torch types; every function returns 0 on success and a
+ * non-zero code on failure, and `clr_last_error()` then returns a message (for a failed
+ * program build it includes the hiprtc log).  Handles are opaque pointers owned by the caller,
+ * who must destroy them.  Device buffers are raw device addresses (`void *`), so memory
+ * allocated elsewhere in the process (e.g. a torch tensor's data_ptr) can be passed in.
+ * `stream` arguments are `hipStream_t` values cast to `void *`; NULL is the default stream.
+ * One host thread per context; contexts of different GPUs are independent.
+ */
+#ifndef CLRAY_HIP_H
+#define CLRAY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct clr_ctx clr_ctx;
+typedef struct clr_program clr_program;
+
+typedef struct clr_device_info_t {
+    char name[128];
+    char arch[64];            /* e.g. "gfx950:sramecc+:xnack-" */
+    int compute_units;
+    int clock_khz;            /* peak shader clock */
+    int wavefront_size;
+    int lds_bytes_per_block;
+    uint64_t global_mem_bytes;
+} clr_device_info_t;
+
+/* Message for the most recent failure on this thread (never NULL). */
+const char *clr_last_error(void);
+
+/* ---- context: replaces Accelerator.__init__ (accelerator.py:17-34) and finish (:36-41) */
+int clr_ctx_create(int device_index, clr_ctx **out);
+int clr_ctx_destroy(clr_ctx *ctx);
+int clr_device_info(clr_ctx *ctx, clr_device_info_t *out);
+int clr_sync(clr_ctx *ctx, void *stream);
+
+/* ---- program: replaces Accelerator.build_program (accelerator.py:43-49).  `source` is the
+ * scene-specialised HIP translation unit; it is compiled with hiprtc for gfx950 (or for
+ * `arch` when not NULL) and loaded as a module on the context's device. */
+int clr_program_build(clr_ctx *ctx, const char *source, int n_options, const char **options,
+                      clr_program **out);
+int clr_program_destroy(clr_program *prog);
+/* Copies `bytes` from host memory into the module-scope device variable `name`
+ * (the __constant__ scene tables: parameters, data offsets, materials). */
+int clr_program_set_global(clr_program *prog, const char *name, const void *host, size_t bytes);
+/* Compile only (no device needed): returns the code-object size; used by the build check. */
+int clr_compile_only(const char *source, int n_options, const char **options, const char *arch,
+                     size_t *code_size);
+
+/* ---- buffers: replace to_device / new_array / new_const_buffer / enqueue_copy / Array.fill /
+ * Array.get (accelerator.py:91-153, renderer.py:306-311) */
+int clr_buffer_alloc(clr_ctx *ctx, size_t bytes, void **device_ptr);
+int clr_buffer_free(clr_ctx *ctx, void *device_ptr);
+int clr_buffer_upload(clr_ctx *ctx, void *device_ptr, const void *host, size_t bytes, void *stream);
+int clr_buffer_download(clr_ctx *ctx, void *host, const void *device_ptr, size_t bytes, void *stream);
+int clr_buffer_fill32(clr_ctx *ctx, void *device_ptr, uint32_t value, size_t count, void *stream);
+
+/* ---- generic launch: replaces Accelerator.call (accelerator.py:63-89) for step-wise kernels.
+ * args[i] points to the i-th kernel argument.  If elapsed_ms is not NULL the launch is
+ * bracketed by HIP events on `stream` and the call waits for it. */
+int clr_launch(clr_program *prog, const char *kernel, const unsigned grid[3],
+               const unsigned block[3], int n_args, void **args, void *stream, float *elapsed_ms);
+
+/* ---- the hot path: replaces the whole of Renderer.render_sample + compute_next_path_segment
+ * (renderer.py:293-433) for `n_passes` consecutive sample passes. */
+typedef struct clr_render_args {
+    void *img;                 /* n_pixels x float4, running sum per pixel (blocked pixel order) */
+    const void *cam;           /* n_pixels x float4, un-jittered primary ray per pixel */
+    const void *pass_tape;     /* n_passes x 6 float4: camera sample per pass */
+    const void *bounce_tape;   /* n_passes x max_bounces x 5 float4: random tape per segment */
+    const void *material_rows; /* spectral mode: n_passes x 10*(n_objects+1) floats; else NULL */
+    const void *vector_data;   /* mesh vertices / normals (float4) or NULL */
+    const void *integer_data;  /* mesh faces / octree stream (int32) or NULL */
+    int n_pixels;
+    int n_passes;
+    int regenerate;            /* 1: a lane starts its next pass as soon as its path ends */
+    void *debug_dump;          /* optional: max_bounces x n_pixels x 6 float4 (n_passes must be 1) */
+} clr_render_args;
+
+int clr_render_passes(clr_program *prog, const clr_render_args *args, void *stream,
+                      float *elapsed_ms);
+
+/* First-hit AOV for the primary rays of the first pass record: ids = (object, sub-object) pairs. */
+int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape,
+                  const void *vector_data, const void *integer_data, int n_pixels,
+                  void *out_ids, void *out_t, void *out_normal, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

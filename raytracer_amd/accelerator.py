@@ -1,0 +1,300 @@
+"""Device abstraction: a thin ctypes layer over the C ABI of ``libclray_hip.so``.
+
+Plays the role of the reference's ``Accelerator`` (/root/reference/accelerator.py:11-229,
+a pyopencl wrapper) with the same method names where the Renderer uses them:
+``build_program``, ``call``, ``enqueue_copy``, ``to_device``, ``new_array``,
+``new_const_buffer``, ``new_vec3_array``, ``make_vec3_array``, ``finish``,
+``output_profiling_info``.  There is no CPU fallback: without the library or without a GPU
+every constructor raises.
+"""
+import ctypes
+import os
+import time
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, 'libclray_hip.so')
+
+
+class ClrError(RuntimeError):
+    pass
+
+
+class DeviceInfo(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 128), ('arch', ctypes.c_char * 64),
+                ('compute_units', ctypes.c_int), ('clock_khz', ctypes.c_int),
+                ('wavefront_size', ctypes.c_int), ('lds_bytes_per_block', ctypes.c_int),
+                ('global_mem_bytes', ctypes.c_uint64)]
+
+
+class RenderArgs(ctypes.Structure):
+    _fields_ = [('img', ctypes.c_void_p), ('cam', ctypes.c_void_p),
+                ('pass_tape', ctypes.c_void_p), ('bounce_tape', ctypes.c_void_p),
+                ('material_rows', ctypes.c_void_p), ('vector_data', ctypes.c_void_p),
+                ('integer_data', ctypes.c_void_p), ('n_pixels', ctypes.c_int),
+                ('n_passes', ctypes.c_int), ('regenerate', ctypes.c_int),
+                ('debug_dump', ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libclray_hip.so and declare the prototypes of include/clray_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBRARY_PATH):
+        raise ClrError("%s is missing: build it with `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (needs hipcc)" % LIBRARY_PATH)
+    lib = ctypes.CDLL(LIBRARY_PATH)
+    vp, ci, cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p
+    P = ctypes.POINTER
+    sigs = {
+        'clr_last_error': (cp, []),
+        'clr_ctx_create': (ci, [ci, P(vp)]),
+        'clr_ctx_destroy': (ci, [vp]),
+        'clr_device_info': (ci, [vp, P(DeviceInfo)]),
+        'clr_sync': (ci, [vp, vp]),
+        'clr_program_build': (ci, [vp, cp, ci, P(cp), P(vp)]),
+        'clr_program_destroy': (ci, [vp]),
+        'clr_program_set_global': (ci, [vp, cp, vp, ctypes.c_size_t]),
+        'clr_compile_only': (ci, [cp, ci, P(cp), cp, P(ctypes.c_size_t)]),
+        'clr_buffer_alloc': (ci, [vp, ctypes.c_size_t, P(vp)]),
+        'clr_buffer_free': (ci, [vp, vp]),
+        'clr_buffer_upload': (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
+        'clr_buffer_download': (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
+        'clr_buffer_fill32': (ci, [vp, vp, ctypes.c_uint32, ctypes.c_size_t, vp]),
+        'clr_launch': (ci, [vp, cp, P(ctypes.c_uint), P(ctypes.c_uint), ci, P(vp), vp,
+                            P(ctypes.c_float)]),
+        'clr_render_passes': (ci, [vp, P(RenderArgs), vp, P(ctypes.c_float)]),
+        'clr_first_hit': (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise ClrError(load_library().clr_last_error().decode('utf-8', 'replace'))
+
+
+def _options_array(options):
+    options = [o.encode() for o in options]
+    arr = (ctypes.c_char_p * max(len(options), 1))(*options)
+    return arr, len(options)
+
+
+def compile_only(source, options=(), arch='gfx950'):
+    """hiprtc-compile `source` without touching a device; returns the code-object size."""
+    lib = load_library()
+    arr, n = _options_array(options)
+    size = ctypes.c_size_t(0)
+    _check(lib.clr_compile_only(source.encode('ascii'), n, arr, arch.encode(), ctypes.byref(size)))
+    return size.value
+
+
+class DeviceArray:
+    """A typed view of device memory (the pyopencl ``Array`` operations the Renderer needs)."""
+
+    def __init__(self, acc, shape, dtype, ptr=None, owner=None):
+        self.acc = acc
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._owner = owner
+        if ptr is None:
+            p = ctypes.c_void_p()
+            _check(acc.lib.clr_buffer_alloc(acc.ctx, self.nbytes, ctypes.byref(p)))
+            self.ptr = p.value
+            self._owned = True
+        else:
+            self.ptr = ptr
+            self._owned = False
+
+    def __del__(self):
+        if getattr(self, '_owned', False) and self.acc.ctx:
+            self.acc.lib.clr_buffer_free(self.acc.ctx, ctypes.c_void_p(self.ptr))
+            self._owned = False
+
+    @property
+    def data(self):
+        return self.ptr
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.nbytes == self.nbytes, (host.shape, self.shape)
+        _check(self.acc.lib.clr_buffer_upload(self.acc.ctx, ctypes.c_void_p(self.ptr),
+                                              host.ctypes.data_as(ctypes.c_void_p), self.nbytes, None))
+        return self
+
+    def get(self):
+        host = np.empty(self.shape, dtype=self.dtype)
+        _check(self.acc.lib.clr_buffer_download(self.acc.ctx, host.ctypes.data_as(ctypes.c_void_p),
+                                                ctypes.c_void_p(self.ptr), self.nbytes, None))
+        return host
+
+    def fill(self, value):
+        assert self.dtype.itemsize == 4
+        bits = int(np.array(value, dtype=self.dtype).view(np.uint32))
+        _check(self.acc.lib.clr_buffer_fill32(self.acc.ctx, ctypes.c_void_p(self.ptr), bits,
+                                              self.nbytes // 4, None))
+        return self
+
+    def __getitem__(self, key):
+        if not (isinstance(key, slice) and key.step is None):
+            raise TypeError("only contiguous slices of the first axis are supported")
+        start, stop, _ = key.indices(self.shape[0])
+        row = self.nbytes // max(self.shape[0], 1)
+        return DeviceArray(self.acc, (max(stop - start, 0),) + self.shape[1:], self.dtype,
+                           ptr=self.ptr + start * row, owner=self)
+
+
+class Accelerator:
+
+    warp_size = 64          # wavefront width of gfx950
+
+    def __init__(self, device_index=0):
+        self.lib = load_library()
+        ctx = ctypes.c_void_p()
+        self.ctx = None
+        _check(self.lib.clr_ctx_create(int(device_index), ctypes.byref(ctx)))
+        self.ctx = ctx
+        self.prog = None
+        self.profiling_info = {}
+        self.last_code = None
+
+    def close(self):
+        if self.prog is not None:
+            self.lib.clr_program_destroy(self.prog)
+            self.prog = None
+        if self.ctx:
+            self.lib.clr_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def device_info(self):
+        info = DeviceInfo()
+        _check(self.lib.clr_device_info(self.ctx, ctypes.byref(info)))
+        return {f: (getattr(info, f).decode() if isinstance(getattr(info, f), bytes) else getattr(info, f))
+                for f, _ in DeviceInfo._fields_}
+
+    def finish(self, stream=None):
+        _check(self.lib.clr_sync(self.ctx, stream))
+
+    # ---- program
+    def build_program(self, prog_code, options=()):
+        if isinstance(options, str):
+            options = options.split()
+        self.last_code = prog_code
+        if self.prog is not None:
+            self.lib.clr_program_destroy(self.prog)
+            self.prog = None
+        arr, n = _options_array(options)
+        prog = ctypes.c_void_p()
+        _check(self.lib.clr_program_build(self.ctx, prog_code.encode('ascii'), n, arr, ctypes.byref(prog)))
+        self.prog = prog
+        return prog
+
+    def set_global(self, name, host):
+        host = np.ascontiguousarray(host)
+        _check(self.lib.clr_program_set_global(self.prog, name.encode(),
+                                               host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+
+    def _record(self, name, device_seconds, host_seconds):
+        info = self.profiling_info.setdefault(name, {'n': 0, 't': 0.0, 'ta': 0.0})
+        info['n'] += 1
+        info['t'] += device_seconds
+        info['ta'] += host_seconds
+
+    def call(self, kernel_name, ndrange_size, buffer_args, value_args=(), work_group_size=None,
+             stream=None):
+        """Launch a kernel of the program over `ndrange_size` work items (1-D or 2-D)."""
+        t0 = time.time()
+        if isinstance(ndrange_size, int):
+            ndrange_size = (ndrange_size,)
+        block = [256, 1, 1] if work_group_size is None else list(work_group_size) + [1] * (3 - len(work_group_size))
+        grid = [1, 1, 1]
+        for i, n in enumerate(ndrange_size):
+            grid[i] = (int(n) + block[i] - 1) // block[i]
+        holders = []
+        for a in tuple(buffer_args) + tuple(value_args):
+            if isinstance(a, DeviceArray):
+                holders.append(ctypes.c_void_p(a.ptr))
+            elif a is None:
+                holders.append(ctypes.c_void_p(0))
+            elif isinstance(a, (np.integer, int)):
+                holders.append(ctypes.c_int(int(a)))
+            elif isinstance(a, (np.floating, float)):
+                holders.append(ctypes.c_float(float(a)))
+            else:
+                raise TypeError("unsupported kernel argument %r" % (a,))
+        argv = (ctypes.c_void_p * len(holders))(*[ctypes.cast(ctypes.pointer(h), ctypes.c_void_p) for h in holders])
+        ms = ctypes.c_float(0)
+        _check(self.lib.clr_launch(self.prog, kernel_name.encode(), (ctypes.c_uint * 3)(*grid),
+                                   (ctypes.c_uint * 3)(*block), len(holders), argv, stream,
+                                   ctypes.byref(ms)))
+        self._record(kernel_name, ms.value * 1e-3, time.time() - t0)
+
+    def render_passes(self, args, stream=None, timed=True):
+        t0 = time.time()
+        ms = ctypes.c_float(0)
+        _check(self.lib.clr_render_passes(self.prog, ctypes.byref(args), stream,
+                                          ctypes.byref(ms) if timed else None))
+        if timed:
+            self._record('clr_render', ms.value * 1e-3, time.time() - t0)
+        return ms.value
+
+    # ---- buffers
+    def enqueue_copy(self, dest, src):
+        if isinstance(dest, DeviceArray):
+            dest.set(np.asarray(src).reshape(dest.shape) if np.size(src) == int(np.prod(dest.shape)) else src)
+        else:
+            np.copyto(dest, src.get())
+
+    def to_device(self, cpuarray):
+        return DeviceArray(self, cpuarray.shape, cpuarray.dtype).set(cpuarray)
+
+    def new_array(self, shape, datatype=np.float32, zeros=False):
+        arr = DeviceArray(self, shape, datatype)
+        if zeros:
+            arr.fill(0)
+        return arr
+
+    def new_const_buffer(self, buf, dtype=np.float32):
+        return self.to_device(np.ascontiguousarray(buf, dtype=dtype))
+
+    def new_vec3_array(self, shape):
+        return self.new_array(tuple(shape) + (4,), np.float32, True)
+
+    @staticmethod
+    def host_vec3_array(a):
+        """(…, 3) -> (…, 4) float32 with a zero fourth lane (float3 storage = float4)."""
+        a = np.asarray(a)
+        assert a.shape[-1] == 3
+        out = np.zeros(a.shape[:-1] + (4,), dtype=np.float32)
+        out[..., :3] = a
+        return out
+
+    def make_vec3_array(self, a):
+        return self.to_device(self.host_vec3_array(a))
+
+    make_const_vec3_buffer = make_vec3_array
+
+    def empty_like(self, a):
+        return DeviceArray(self, a.shape, a.dtype)
+
+    def zeros_like(self, a):
+        return DeviceArray(self, a.shape, a.dtype).fill(0)
+
+    def output_profiling_info(self):
+        total = host_total = 0.0
+        for name, v in self.profiling_info.items():
+            n = v['n']
+            print('%d\t%.2g\t%.2g\t%.2g\t%.2g\t%s' % (n, v['t'], v['ta'], v['t'] / n, v['ta'] / n, name))
+            total += v['t']
+            host_total += v['ta']
+        print('----', total, 'or', host_total, 'seconds total')

@@ -1,0 +1,275 @@
+// libclray_hip.so - host side of the MI355X back end (see include/clray_hip.h).
+// Compiles scene-specialised HIP source with hiprtc for gfx950, loads it as a module and
+// launches its kernels.  No device code lives in this file.
+#include "clray_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error = "";
+
+int fail(const std::string &what) {
+    g_error = what;
+    return 1;
+}
+
+int check(hipError_t e, const char *what) {
+    if (e == hipSuccess) return 0;
+    return fail(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define CLR_TRY(expr) do { if (int rc_ = check((expr), #expr)) return rc_; } while (0)
+
+const unsigned kBlock = 256;
+
+}  // namespace
+
+struct clr_ctx {
+    int device;
+    hipEvent_t ev_start, ev_stop;
+};
+
+struct clr_program {
+    clr_ctx *ctx;
+    hipModule_t module;
+    hipFunction_t render, first_hit;
+};
+
+namespace {
+
+int compile(const char *source, int n_options, const char **options, const std::string &arch,
+            std::vector<char> &code) {
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, source, "clray_scene.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail("hiprtcCreateProgram failed");
+    std::vector<std::string> opts;
+    opts.push_back("--offload-arch=" + arch);
+    for (int i = 0; i < n_options; ++i) opts.push_back(options[i]);
+    std::vector<const char *> raw;
+    for (auto &o : opts) raw.push_back(o.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)raw.size(), raw.data());
+    size_t log_size = 0;
+    hiprtcGetProgramLogSize(prog, &log_size);
+    std::string log(log_size, '\0');
+    if (log_size) hiprtcGetProgramLog(prog, &log[0]);
+    if (r != HIPRTC_SUCCESS) {
+        hiprtcDestroyProgram(&prog);
+        return fail(std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+    }
+    size_t size = 0;
+    hiprtcGetCodeSize(prog, &size);
+    code.resize(size);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return 0;
+}
+
+int set_device(clr_ctx *ctx) {
+    if (!ctx) return fail("null context");
+    return check(hipSetDevice(ctx->device), "hipSetDevice");
+}
+
+int launch(clr_ctx *ctx, hipFunction_t fn, const unsigned grid[3], const unsigned block[3],
+           void **args, void *stream, float *elapsed_ms) {
+    hipStream_t s = (hipStream_t)stream;
+    if (elapsed_ms) CLR_TRY(hipEventRecord(ctx->ev_start, s));
+    CLR_TRY(hipModuleLaunchKernel(fn, grid[0], grid[1], grid[2], block[0], block[1], block[2],
+                                  0, s, args, nullptr));
+    if (elapsed_ms) {
+        CLR_TRY(hipEventRecord(ctx->ev_stop, s));
+        CLR_TRY(hipEventSynchronize(ctx->ev_stop));
+        CLR_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *clr_last_error(void) { return g_error.c_str(); }
+
+int clr_ctx_create(int device_index, clr_ctx **out) {
+    if (!out) return fail("null output pointer");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail("no HIP device available: libclray_hip needs an AMD GPU (gfx950)");
+    if (device_index < 0 || device_index >= count) return fail("device index out of range");
+    CLR_TRY(hipSetDevice(device_index));
+    clr_ctx *ctx = new clr_ctx;
+    ctx->device = device_index;
+    if (int rc = check(hipEventCreate(&ctx->ev_start), "hipEventCreate")) { delete ctx; return rc; }
+    if (int rc = check(hipEventCreate(&ctx->ev_stop), "hipEventCreate")) { delete ctx; return rc; }
+    *out = ctx;
+    return 0;
+}
+
+int clr_ctx_destroy(clr_ctx *ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipEventDestroy(ctx->ev_start);
+    (void)hipEventDestroy(ctx->ev_stop);
+    delete ctx;
+    return 0;
+}
+
+int clr_device_info(clr_ctx *ctx, clr_device_info_t *out) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!out) return fail("null output pointer");
+    hipDeviceProp_t p;
+    CLR_TRY(hipGetDeviceProperties(&p, ctx->device));
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", p.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", p.gcnArchName);
+    out->compute_units = p.multiProcessorCount;
+    out->clock_khz = p.clockRate;
+    out->wavefront_size = p.warpSize;
+    out->lds_bytes_per_block = (int)p.sharedMemPerBlock;
+    out->global_mem_bytes = p.totalGlobalMem;
+    return 0;
+}
+
+int clr_sync(clr_ctx *ctx, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    CLR_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int clr_compile_only(const char *source, int n_options, const char **options, const char *arch,
+                     size_t *code_size) {
+    if (!source) return fail("null source");
+    std::vector<char> code;
+    if (int rc = compile(source, n_options, options, arch ? arch : "gfx950", code)) return rc;
+    if (code_size) *code_size = code.size();
+    return 0;
+}
+
+int clr_program_build(clr_ctx *ctx, const char *source, int n_options, const char **options,
+                      clr_program **out) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!source || !out) return fail("null argument");
+    hipDeviceProp_t p;
+    CLR_TRY(hipGetDeviceProperties(&p, ctx->device));
+    std::vector<char> code;
+    if (int rc = compile(source, n_options, options, p.gcnArchName, code)) return rc;
+    clr_program *prog = new clr_program;
+    prog->ctx = ctx;
+    if (int rc = check(hipModuleLoadData(&prog->module, code.data()), "hipModuleLoadData")) {
+        delete prog;
+        return rc;
+    }
+    if (check(hipModuleGetFunction(&prog->render, prog->module, "clr_render"), "clr_render") ||
+        check(hipModuleGetFunction(&prog->first_hit, prog->module, "clr_first_hit"), "clr_first_hit")) {
+        (void)hipModuleUnload(prog->module);
+        delete prog;
+        return 1;
+    }
+    *out = prog;
+    return 0;
+}
+
+int clr_program_destroy(clr_program *prog) {
+    if (!prog) return 0;
+    (void)hipSetDevice(prog->ctx->device);
+    (void)hipModuleUnload(prog->module);
+    delete prog;
+    return 0;
+}
+
+int clr_program_set_global(clr_program *prog, const char *name, const void *host, size_t bytes) {
+    if (!prog || !name || !host) return fail("null argument");
+    if (int rc = set_device(prog->ctx)) return rc;
+    hipDeviceptr_t dptr;
+    size_t size = 0;
+    CLR_TRY(hipModuleGetGlobal(&dptr, &size, prog->module, name));
+    if (bytes > size)
+        return fail(std::string("clr_program_set_global: ") + name + " holds " + std::to_string(size) +
+                    " bytes, asked to write " + std::to_string(bytes));
+    CLR_TRY(hipMemcpyHtoD(dptr, const_cast<void *>(host), bytes));
+    return 0;
+}
+
+int clr_buffer_alloc(clr_ctx *ctx, size_t bytes, void **device_ptr) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!device_ptr) return fail("null output pointer");
+    CLR_TRY(hipMalloc(device_ptr, bytes ? bytes : 4));
+    return 0;
+}
+
+int clr_buffer_free(clr_ctx *ctx, void *device_ptr) {
+    if (int rc = set_device(ctx)) return rc;
+    CLR_TRY(hipFree(device_ptr));
+    return 0;
+}
+
+int clr_buffer_upload(clr_ctx *ctx, void *device_ptr, const void *host, size_t bytes, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    CLR_TRY(hipMemcpyAsync(device_ptr, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    CLR_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int clr_buffer_download(clr_ctx *ctx, void *host, const void *device_ptr, size_t bytes, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    CLR_TRY(hipMemcpyAsync(host, device_ptr, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CLR_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int clr_buffer_fill32(clr_ctx *ctx, void *device_ptr, uint32_t value, size_t count, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    CLR_TRY(hipMemsetD32Async((hipDeviceptr_t)device_ptr, (int)value, count, (hipStream_t)stream));
+    return 0;
+}
+
+int clr_launch(clr_program *prog, const char *kernel, const unsigned grid[3],
+               const unsigned block[3], int n_args, void **args, void *stream, float *elapsed_ms) {
+    if (!prog || !kernel) return fail("null argument");
+    (void)n_args;
+    if (int rc = set_device(prog->ctx)) return rc;
+    hipFunction_t fn;
+    CLR_TRY(hipModuleGetFunction(&fn, prog->module, kernel));
+    return launch(prog->ctx, fn, grid, block, args, stream, elapsed_ms);
+}
+
+int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms) {
+    if (!prog || !a) return fail("null argument");
+    if (int rc = set_device(prog->ctx)) return rc;
+    if (a->n_pixels <= 0 || a->n_passes < 0) return fail("clr_render_passes: bad n_pixels / n_passes");
+    if (!a->img || !a->cam || !a->pass_tape || !a->bounce_tape)
+        return fail("clr_render_passes: img, cam, pass_tape and bounce_tape are required");
+    if (a->debug_dump && a->n_passes != 1)
+        return fail("clr_render_passes: debug_dump needs n_passes == 1");
+    if (a->n_passes == 0) { if (elapsed_ms) *elapsed_ms = 0.0f; return 0; }
+    void *img = a->img;
+    const void *cam = a->cam, *pt = a->pass_tape, *bt = a->bounce_tape, *mr = a->material_rows,
+               *vd = a->vector_data, *id = a->integer_data;
+    int n_pixels = a->n_pixels, n_passes = a->n_passes, regen = a->regenerate;
+    void *dbg = a->debug_dump;
+    void *args[] = {&img, &cam, &pt, &bt, &mr, &vd, &id, &n_pixels, &n_passes, &regen, &dbg};
+    const unsigned grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
+    const unsigned block[3] = {kBlock, 1, 1};
+    return launch(prog->ctx, prog->render, grid, block, args, stream, elapsed_ms);
+}
+
+int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape, const void *vector_data,
+                  const void *integer_data, int n_pixels, void *out_ids, void *out_t,
+                  void *out_normal, void *stream) {
+    if (!prog) return fail("null argument");
+    if (int rc = set_device(prog->ctx)) return rc;
+    if (n_pixels <= 0 || !cam || !pass_tape || !out_ids || !out_t || !out_normal)
+        return fail("clr_first_hit: bad arguments");
+    void *args[] = {&cam, &pass_tape, &vector_data, &integer_data, &n_pixels, &out_ids, &out_t, &out_normal};
+    const unsigned grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
+    const unsigned block[3] = {kBlock, 1, 1};
+    return launch(prog->ctx, prog->first_hit, grid, block, args, stream, nullptr);
+}
+
+}  // extern "C"

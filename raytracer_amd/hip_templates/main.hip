@@ -1,0 +1,244 @@
+{#- Program skeleton: one scene-specialised HIP translation unit, compiled with hiprtc.
+    Counterpart of the reference's main.cl (/root/reference/cl_templates/main.cl:2-30) plus
+    the launch schedule of renderer.py:293-433, which here runs on the device: each lane
+    owns one pixel and walks its sample passes and path segments in registers. -#}
+{% include 'static.hip' %}
+
+// ---- scene tables, filled by the host after the module is loaded
+__constant__ float4 clr_params[{{ [renderer.n_param_slots, 1]|max }}];     // per object: declared parameters, then 4 rows of the inverse affine
+__constant__ int clr_data_offsets[{{ [2*n_objects, 2]|max }}];              // per object: offset into vector_data, integer_data
+### if shader.rgb
+__constant__ float4 clr_material_colors[{{ 5*(n_objects+1) }}];
+__constant__ float clr_material_scalars[{{ 5*(n_objects+1) }}];
+### endif
+
+{% include 'shader.hip' %}
+
+// ---- shape functions
+### for k in functions.declarations
+{{ k }}
+### endfor
+
+### for k in functions.definitions
+{{ k }}
+### endfor
+
+// ---- per-class steps
+### for k in functions.kernels
+{{ k }}
+### endfor
+
+#define CLR_MAX_BOUNCES {{ renderer.scene.max_bounces }}
+#define CLR_MAX_RAY_LENGTH {{ renderer.scene.max_ray_length|float }}f
+#define CLR_N_OBJECTS {{ n_objects }}
+#define CLR_PASS_STRIDE 6
+#define CLR_BOUNCE_STRIDE 5
+#define CLR_MATERIAL_ROW {{ 10*(n_objects+1) }}
+
+// closest hit over every object of the scene (renderer.py:338-344)
+CLR_FN void clr_closest_hit(const vec3 pos, const vec3 ray, float &isec_dist, uint &whichobject,
+    uint &which_subobject, const uint last_whichobject, const uint last_which_subobject,
+    const uint inside, const float4 * __restrict__ vector_data, const int * __restrict__ integer_data)
+{
+### for tracer, count, offset in renderer.object_groups
+    #pragma unroll {{ [count, 8]|min }}
+    for (int i = 0; i < {{ count }}; ++i)
+        {{ tracer.tracer_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject,
+            last_whichobject, last_which_subobject, inside, vector_data, integer_data,
+            {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[loop.index0] }} + i*{{ renderer.group_param_stride[loop.index0] }});
+### endfor
+}
+
+// normal of the object that was hit (renderer.py:346-351)
+CLR_FN vec3 clr_surface_normal(const vec3 pos, const vec3 ray, const uint whichobject,
+    const uint which_subobject, const uint inside,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data)
+{
+### for tracer, count, offset in renderer.object_groups
+    {% if not loop.first %}else {% endif %}if (whichobject >= {{ offset+1 }} && whichobject < {{ offset+1+count }})
+        return {{ tracer.normal_kernel_name }}(pos, ray, which_subobject, inside, vector_data, integer_data,
+            (int)whichobject, clr_params + {{ renderer.group_param_base[loop.index0] }} + (whichobject - {{ offset+1 }})*{{ renderer.group_param_stride[loop.index0] }});
+### endfor
+    return make_vec3(0.0f, 0.0f, 0.0f);
+}
+
+### if renderer.bidirectional
+// visibility of the light point from the hit point (renderer.py:373-382, tracer.cl:143-221)
+CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint whichobject,
+    const uint which_subobject, const uint inside, const int diffusions_left,
+    const vec3 dest, const int light_id,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data)
+{
+    if (diffusions_left < 1) return 0.0f;
+    vec3 ray = dest - pos;
+    if (dot(normal, ray) < 0.0f) return 0.0f;
+    const float isec_dist = length(ray);
+    ray = ray / isec_dist;
+    float shadow_mask = 1.0f;
+### for tracer, count, offset in renderer.object_groups
+    #pragma unroll {{ [count, 8]|min }}
+    for (int i = 0; i < {{ count }}; ++i)
+        if ({{ offset+1 }} + i != light_id)
+            {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,
+                shadow_mask, vector_data, integer_data,
+                {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[loop.index0] }} + i*{{ renderer.group_param_stride[loop.index0] }});
+### endfor
+    return shadow_mask;
+}
+### endif
+
+CLR_FN BounceSample clr_load_bounce(const float4 * __restrict__ rec) {
+    BounceSample B;
+    const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3], e = rec[4];
+    B.rvec = make_vec3(a); B.p = a.w;
+    B.gauss = make_vec3(b); B.russian = b.w;
+    B.light_point = make_vec3(c); B.light_area = c.w;
+    B.light_normal = make_vec3(d); B.min_light_sampling_distance = d.w;
+    B.light_center = make_vec3(e); B.light_id = __float_as_int(e.w);
+    return B;
+}
+
+// primary ray of one pass (static.cl:109-131): rows of the jitter rotation in rec[0..2],
+// rec[3] = (dof offset, sharp distance), rec[4] = (camera origin, initial path colour scale)
+CLR_FN void clr_start_path(PathState &s, const float4 * __restrict__ rec, const vec3 base_ray) {
+    const vec3 rot_ray = make_vec3(dot(make_vec3(rec[0]), base_ray), dot(make_vec3(rec[1]), base_ray),
+                                   dot(make_vec3(rec[2]), base_ray));
+    const float sharp_distance = rec[3].w;
+    if (sharp_distance > 0.0f) s.ray = fast_normalize(sharp_distance * rot_ray - make_vec3(rec[3]));
+    else s.ray = rot_ray;
+    s.pos = make_vec3(rec[4]);
+    s.ray_color = COLOR_ONE * rec[4].w;
+    s.whichobject = 0;
+    s.which_subobject = 0;
+    s.inside = {{ renderer.root_object_id }};
+    s.diffusions_left = {{ renderer.scene.min_bounces }};
+    s.suppress_emission = 0;
+}
+
+#define CLR_DBG_STRIDE 6   // float4 records per (segment, pixel) in the debug dump
+
+// One path segment: closest hit, normal, light visibility, shading, roulette
+// (renderer.py:326-433).  Returns false when the path ends.
+CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last, const vec3 cmask,
+    vec3 &img, const float * __restrict__ material_row,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
+    float4 * __restrict__ dbg)
+{
+    float isec_dist = CLR_MAX_RAY_LENGTH;
+    const uint last_whichobject = s.whichobject, last_which_subobject = s.which_subobject;
+    uint whichobject = 0, which_subobject = last_which_subobject;
+    clr_closest_hit(s.pos, s.ray, isec_dist, whichobject, which_subobject,
+                    last_whichobject, last_which_subobject, s.inside, vector_data, integer_data);
+    if (whichobject == 0) {
+        // open scene: the reference leaves this case undefined; end the path
+        if (dbg) { dbg[0] = make_float4(0.0f, 0.0f, __int_as_float((int)s.inside), __int_as_float(s.diffusions_left));
+                   dbg[1] = make_float4(isec_dist, 0.0f, 0.0f, 0.0f); }
+        return false;
+    }
+    s.whichobject = whichobject;
+    s.which_subobject = which_subobject;
+    s.pos += isec_dist * s.ray;
+    const vec3 normal = clr_surface_normal(s.pos, s.ray, whichobject, which_subobject, s.inside,
+                                           vector_data, integer_data);
+    float shadow_mask = 0.0f;
+### if renderer.bidirectional
+    if (!is_last)
+        shadow_mask = clr_light_visibility(s.pos, normal, whichobject, which_subobject, s.inside,
+            s.diffusions_left, B.light_point, B.light_id, vector_data, integer_data);
+### endif
+    const vec3 hit_pos = s.pos;
+    const bool alive = clr_shade(s, normal, isec_dist, shadow_mask, B, is_last, cmask, img
+### if not shader.rgb
+        , material_row
+### endif
+        );
+    if (dbg) {
+        dbg[0] = make_float4(__int_as_float((int)whichobject), __int_as_float((int)which_subobject),
+                             __int_as_float((int)s.inside), __int_as_float(s.diffusions_left));
+        dbg[1] = make_float4(isec_dist, alive ? 1.0f : 0.0f, shadow_mask, __int_as_float(s.suppress_emission));
+        dbg[2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, 0.0f);
+        dbg[3] = make_float4(s.ray.x, s.ray.y, s.ray.z, 0.0f);
+        dbg[4] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+        const vec3 c = color_to_rgb(s.ray_color, make_vec3(1.0f, 1.0f, 1.0f));
+        dbg[5] = make_float4(c.x, c.y, c.z, 0.0f);
+    }
+    return alive;
+}
+
+// ---------------------------------------------------------------------------------------
+// Render kernel.  Lane k owns pixel k (blocked pixel order) and accumulates its radiance in
+// registers over `n_passes` sample passes; img[k] is read once and written once.
+//   regen = 0: the lanes of a wave start each pass together (finished paths idle until the
+//              slowest path of the wave ends);
+//   regen = 1: a lane starts its next pass as soon as its path ends, so every lane of the wave
+//              always executes a live segment (path regeneration).  Per-pixel results are
+//              identical in both modes: a lane still visits its passes and segments in order.
+// dbg (optional, n_passes == 1): CLR_DBG_STRIDE float4 per (segment, pixel).
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
+           const float4 * __restrict__ pass_tape, const float4 * __restrict__ bounce_tape,
+           const float * __restrict__ material_rows,
+           const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
+           const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_image = k < n_pixels;
+    const int kk = in_image ? k : 0;
+    const vec3 base_ray = make_vec3(cam[kk]);
+    const float4 img0 = img[kk];
+    vec3 acc = make_vec3(img0.x, img0.y, img0.z);
+
+    PathState s;
+    int pass = in_image ? 0 : n_passes;
+    int segment = 0;
+    bool active = false;
+    vec3 cmask = make_vec3(1.0f, 1.0f, 1.0f);
+
+    for (;;) {
+        const bool wave_busy = __any(active);
+        if (!active && pass < n_passes && (regen || !wave_busy)) {
+            const float4 *rec = pass_tape + (size_t)pass * CLR_PASS_STRIDE;
+            clr_start_path(s, rec, base_ray);
+            cmask = make_vec3(rec[5]);
+            segment = 0;
+            active = true;
+        }
+        if (!__any(active)) break;
+        if (active) {
+            const BounceSample B = clr_load_bounce(bounce_tape + ((size_t)pass * CLR_MAX_BOUNCES + segment) * CLR_BOUNCE_STRIDE);
+            const bool is_last = segment == CLR_MAX_BOUNCES - 1;
+            float4 *d = dbg ? dbg + ((size_t)segment * n_pixels + k) * CLR_DBG_STRIDE : nullptr;
+            const bool alive = clr_segment(s, B, is_last, cmask, acc,
+                material_rows + (size_t)pass * CLR_MATERIAL_ROW, vector_data, integer_data, d);
+            segment++;
+            if (!alive) { active = false; pass++; }
+        }
+    }
+    if (in_image) img[k] = make_float4(acc.x, acc.y, acc.z, img0.w);
+}
+
+// First-hit AOV for the primary rays of pass record 0: object id, sub-object, distance, normal.
+extern "C" __global__ void __launch_bounds__(256)
+clr_first_hit(const float4 * __restrict__ cam, const float4 * __restrict__ pass_tape,
+              const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
+              const int n_pixels, int * __restrict__ out_ids, float * __restrict__ out_t,
+              float4 * __restrict__ out_normal)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pixels) return;
+    PathState s;
+    clr_start_path(s, pass_tape, make_vec3(cam[k]));
+    float isec_dist = CLR_MAX_RAY_LENGTH;
+    uint whichobject = 0, which_subobject = 0;
+    clr_closest_hit(s.pos, s.ray, isec_dist, whichobject, which_subobject, 0, 0, s.inside,
+                    vector_data, integer_data);
+    vec3 normal = make_vec3(0.0f, 0.0f, 0.0f);
+    if (whichobject != 0)
+        normal = clr_surface_normal(s.pos + isec_dist * s.ray, s.ray, whichobject, which_subobject,
+                                    s.inside, vector_data, integer_data);
+    out_ids[2*k] = (int)whichobject;
+    out_ids[2*k+1] = (int)which_subobject;
+    out_t[k] = isec_dist;
+    out_normal[k] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+}

@@ -1,0 +1,241 @@
+{#- Material model and the per-segment shading pipeline, fused into one __device__ function.
+    Counterpart of the reference's shader.cl (/root/reference/cl_templates/shader.cl:2-434),
+    where each stage (volumetric, emission, reflection, refraction, diffuse) and the culler are
+    separate kernels that communicate through global buffers.  The stage protocol is kept:
+    one shared sample p in [0,1) is consumed stage by stage; the stage that "fires" sets
+    p = -1, commits the new direction and multiplies the path colour by pipeline_color. -#}
+
+### for item in shader.get_material_property_offsets()
+#define MAT_{{item[0]}} {{item[1]}}
+### endfor
+
+### if shader.rgb
+typedef vec3 color_t;
+#define COLOR(prop, id) make_vec3(clr_material_colors[(prop) + (id)])
+#define COLOR2PROB(color) (dot(color, make_vec3(1.0f, 1.0f, 1.0f))/3.0f)
+#define SCALAR(prop, id) clr_material_scalars[(prop) + (id)]
+#define COLOR_ONE make_vec3(1.0f, 1.0f, 1.0f)
+CLR_FN vec3 color_to_rgb(vec3 c, vec3 cmask) { return c; }
+### else
+typedef float color_t;
+#define COLOR(prop, id) material_scalars[(prop) + (id)]
+#define COLOR2PROB(color) (color)
+#define SCALAR(prop, id) material_scalars[(prop) + (id)]
+#define COLOR_ONE 1.0f
+CLR_FN vec3 color_to_rgb(float c, vec3 cmask) { return c * cmask; }
+### endif
+
+#define CLR_PI_F 3.14159274101257324f
+
+struct PathState {
+    vec3 pos, ray;
+    color_t ray_color;
+    uint whichobject, which_subobject;   // surface the path is on (0 = none)
+    uint inside;                         // object the path travels in (0 = ambient)
+    int diffusions_left;
+    int suppress_emission;
+};
+
+struct BounceSample {                    // one record of the random tape
+    vec3 rvec; float p;                  // unit vector, stage sample
+    vec3 gauss; float russian;           // gaussian vector, Russian-roulette sample
+    vec3 light_point; float light_area;
+    vec3 light_normal; float min_light_sampling_distance;
+    vec3 light_center; int light_id;     // 0 on the last segment / without lights
+};
+
+// Runs the stage pipeline for one path segment that ended at s.pos (surface s.whichobject,
+// normal n, segment length last_dist).  Adds radiance to `img`.  Returns false if the path
+// is finished (last segment, or culled).
+CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const float shadow_mask,
+                      const BounceSample &B, const bool is_last, const vec3 cmask, vec3 &img
+### if not shader.rgb
+                      , const float * __restrict__ material_scalars
+### endif
+                      )
+{
+    float p = B.p;
+    vec3 r = s.ray;
+    vec3 gauss_rvec = B.gauss;
+    float cur_prob = 0.0f;
+    color_t cur_col;
+    color_t pipeline_color;
+
+    // ---- volumetric effects (shader.cl:124-170)
+    {
+        float last_dist = last_distance;
+        const float alpha = SCALAR(MAT_VOLUME_SCATTERING, s.inside);
+        if (alpha > 0) cur_prob = 1.0f - expf(-alpha*last_dist);
+
+        if (p < cur_prob) {
+            // scattering inside the medium at distance d < last_dist along the segment
+            float d = -logf(1.0f - p) / alpha;
+            s.pos -= (last_dist - d) * r;
+            last_dist = d;
+            s.whichobject = 0;
+            const float blur = SCALAR(MAT_VOLUME_SCATTERING_BLUR, s.inside);
+            if (blur < 1.0f) r = normalize(gauss_rvec + r * tanf(CLR_PI_F*0.5f*(1.0f - blur)));
+            else r = B.rvec;
+### if renderer.bidirectional
+            s.suppress_emission = 0;
+### endif
+            p = -1.0f;
+        }
+        else p -= cur_prob;
+
+### if shader.rgb
+        cur_col = COLOR(MAT_VOLUME_ABSORPTION, s.inside);
+        pipeline_color = make_vec3(expf(-cur_col.x*last_dist), expf(-cur_col.y*last_dist), expf(-cur_col.z*last_dist));
+### else
+        pipeline_color = expf(-SCALAR(MAT_VOLUME_ABSORPTION, s.inside)*last_dist);
+### endif
+        if (p < 0.0f) { s.ray = r; s.ray_color = s.ray_color * pipeline_color; }
+    }
+
+    // ---- emission (shader.cl:172-188)
+    if (p >= 0.0f) {
+### if renderer.bidirectional
+        const int suppressed = s.suppress_emission;
+        if ((suppressed >= 0 && s.whichobject != (uint)suppressed) || s.whichobject == (uint)(-suppressed))
+### endif
+        {
+            img += color_to_rgb(COLOR(MAT_EMISSION, s.whichobject) * s.ray_color * pipeline_color, cmask);
+        }
+    }
+
+    if (is_last) return false;
+
+    // ---- specular reflection (shader.cl:190-217)
+    if (p >= 0.0f) {
+        cur_col = COLOR(MAT_REFLECTION, s.whichobject);
+        cur_prob = COLOR2PROB(cur_col);
+        if (p < cur_prob) {
+### if shader.rgb
+            pipeline_color *= cur_col / cur_prob;
+### endif
+            r -= 2*dot(r, n) * n;
+            const float blur = SCALAR(MAT_REFLECTION_BLUR, s.whichobject);
+            if (blur > 0) {
+                if (dot(n, gauss_rvec) < 0) gauss_rvec = -gauss_rvec;
+                r = normalize(gauss_rvec * blur + r * (1.0f - blur));
+            }
+### if renderer.bidirectional
+            s.suppress_emission = 0;
+### endif
+            p = -1.0f;
+            s.ray = r; s.ray_color = s.ray_color * pipeline_color;
+        }
+        else p -= cur_prob;
+    }
+
+    // ---- refraction / transparency (shader.cl:219-288)
+    if (p >= 0.0f) {
+        cur_col = COLOR(MAT_TRANSPARENCY, s.whichobject);
+        cur_prob = COLOR2PROB(cur_col);
+        if (p < cur_prob) {
+### if shader.rgb
+            pipeline_color *= cur_col / cur_prob;
+### endif
+            float dotp = dot(r, n);
+            if (dotp > 0) { n = -n; dotp = -dotp; }
+
+            float nfrac = 0;
+            const float ior1 = SCALAR(MAT_IOR, s.whichobject);
+            const float ior0 = SCALAR(MAT_IOR, 0);
+            if (s.inside == s.whichobject) {         // leaving the object
+                nfrac = ior1/ior0;
+                s.inside = 0;
+            }
+            else {                                   // entering it
+                nfrac = ior0/ior1;
+                s.inside = s.whichobject;
+            }
+
+            if (nfrac != 1) {
+                const float cos2t = 1 - nfrac*nfrac*(1 - dotp*dotp);
+                if (cos2t < 0) {
+                    // total internal reflection: undo the inside bookkeeping
+                    r -= 2*dotp * n;
+                    if (s.inside == s.whichobject) s.inside = 0;
+                    else s.inside = s.whichobject;
+                }
+                else r = normalize(r*nfrac + n*(-dotp*nfrac - sqrtf(cos2t)));
+            }
+
+            if (dot(n, r) < 0) n = -n;
+            const float blur = SCALAR(MAT_TRANSPARENCY_BLUR, s.whichobject);
+            if (blur > 0) {
+                if (dot(n, gauss_rvec) < 0) gauss_rvec = -gauss_rvec;
+                r = normalize(gauss_rvec * blur + r * (1.0f - blur));
+            }
+### if renderer.bidirectional
+            s.suppress_emission = 0;
+### endif
+            p = -1.0f;
+            s.ray = r; s.ray_color = s.ray_color * pipeline_color;
+        }
+        else p -= cur_prob;
+    }
+
+    // ---- diffuse reflection or absorption (shader.cl:291-353)
+    if (p >= 0.0f) {
+### if renderer.bidirectional
+        s.suppress_emission = 0;
+### endif
+        cur_col = COLOR(MAT_DIFFUSE, s.whichobject);
+        cur_prob = COLOR2PROB(cur_col);
+
+        if (cur_prob > 0.0f && s.diffusions_left > 0) {
+            pipeline_color = pipeline_color * cur_col;
+            s.diffusions_left -= 1;
+### if renderer.bidirectional
+            if (B.light_id > 0) {
+                // next-event estimation towards the light point of this segment
+                if (length(s.pos - B.light_center) > B.min_light_sampling_distance) {
+                    vec3 shadow_ray = B.light_point - s.pos;
+                    s.suppress_emission = B.light_id;
+                    if (dot(shadow_ray, n) > 0 && dot(shadow_ray, B.light_normal) < 0) {
+                        const float shadow_dist = length(shadow_ray);
+                        shadow_ray = fast_normalize(shadow_ray);
+                        const float geom = dot(n, shadow_ray) / CLR_PI_F
+                            * dot(-shadow_ray, B.light_normal) / (shadow_dist*shadow_dist);
+                        img += color_to_rgb(geom * s.ray_color * pipeline_color, cmask)
+                            * color_to_rgb(COLOR(MAT_EMISSION, B.light_id), make_vec3(1.0f, 1.0f, 1.0f))
+                            * shadow_mask * B.light_area;
+                    }
+                }
+                else if (s.diffusions_left == 0) {
+                    // too close to the light for a stable estimate: allow one more bounce
+                    s.diffusions_left = 1;
+                    s.suppress_emission = -B.light_id;
+                }
+            }
+### endif
+            r = B.rvec;
+            if (dot(n, r) < 0) r = -r;
+            pipeline_color = pipeline_color * (2.0f * dot(n, r));
+        }
+        else pipeline_color = pipeline_color * 0.0f;
+
+        p = -1.0f;
+        s.ray = r; s.ray_color = s.ray_color * pipeline_color;
+    }
+
+    // ---- Russian roulette (shader.cl:371-434 with a group of one ray)
+    {
+        const float cur_intensity = COLOR2PROB(s.ray_color);
+        float survive = cur_intensity;
+        float russian_prob = 1.0f;
+### if renderer.scene.min_russian_prob
+        if (cur_intensity > 0.0f) {
+            russian_prob = fminf(fmaxf(cur_intensity, {{ renderer.scene.min_russian_prob|float }}f), 1.0f);
+            if (B.russian > russian_prob) survive = 0.0f;
+        }
+### endif
+        if (survive == 0.0f) return false;
+### if renderer.scene.min_russian_prob
+        if (russian_prob < 1.0f) s.ray_color = s.ray_color / russian_prob;
+### endif
+    }
+    return true;
+}

@@ -1,0 +1,118 @@
+{#- Scene-independent device helpers.  Counterpart of the reference's static.cl
+    (/root/reference/cl_templates/static.cl:4-101): vector algebra, affine helpers,
+    interval arithmetic and quaternion products.  Every arithmetic step is written out
+    so that the CPU oracle (oracle/clray_oracle.c) can follow the same order of
+    operations; the translation unit is compiled with -ffp-contract=off in parity mode. -#}
+typedef unsigned int uint;
+
+struct vec3 { float x, y, z; };
+struct vec2 { float x, y; };
+struct vec4 { float x, y, z, w; };
+
+#define CLR_FN static __device__ __forceinline__
+
+CLR_FN vec3 make_vec3(float x, float y, float z) { vec3 v; v.x = x; v.y = y; v.z = z; return v; }
+CLR_FN vec3 make_vec3(float4 f) { return make_vec3(f.x, f.y, f.z); }
+CLR_FN vec2 make_vec2(float x, float y) { vec2 v; v.x = x; v.y = y; return v; }
+CLR_FN vec4 make_vec4(float x, float y, float z, float w) { vec4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
+CLR_FN vec4 make_vec4(vec3 a, float w) { return make_vec4(a.x, a.y, a.z, w); }
+
+CLR_FN vec3 operator+(vec3 a, vec3 b) { return make_vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+CLR_FN vec3 operator-(vec3 a, vec3 b) { return make_vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+CLR_FN vec3 operator*(vec3 a, vec3 b) { return make_vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+CLR_FN vec3 operator/(vec3 a, vec3 b) { return make_vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
+CLR_FN vec3 operator-(vec3 a) { return make_vec3(-a.x, -a.y, -a.z); }
+CLR_FN vec3 operator*(vec3 a, float s) { return make_vec3(a.x * s, a.y * s, a.z * s); }
+CLR_FN vec3 operator*(float s, vec3 a) { return make_vec3(s * a.x, s * a.y, s * a.z); }
+CLR_FN vec3 operator/(vec3 a, float s) { return make_vec3(a.x / s, a.y / s, a.z / s); }
+CLR_FN vec3& operator+=(vec3& a, vec3 b) { a = a + b; return a; }
+CLR_FN vec3& operator-=(vec3& a, vec3 b) { a = a - b; return a; }
+CLR_FN vec3& operator*=(vec3& a, vec3 b) { a = a * b; return a; }
+CLR_FN vec3& operator*=(vec3& a, float s) { a = a * s; return a; }
+
+CLR_FN vec2 operator+(vec2 a, vec2 b) { return make_vec2(a.x + b.x, a.y + b.y); }
+CLR_FN vec2 operator+(vec2 a, float s) { return make_vec2(a.x + s, a.y + s); }
+CLR_FN vec2 operator-(vec2 a, float s) { return make_vec2(a.x - s, a.y - s); }
+CLR_FN vec2 operator*(vec2 a, vec2 b) { return make_vec2(a.x * b.x, a.y * b.y); }
+CLR_FN vec2 operator*(vec2 a, float s) { return make_vec2(a.x * s, a.y * s); }
+CLR_FN vec2 operator*(float s, vec2 a) { return make_vec2(s * a.x, s * a.y); }
+
+CLR_FN vec4 operator+(vec4 a, vec4 b) { return make_vec4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+CLR_FN vec4 operator*(float s, vec4 a) { return make_vec4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// dot / cross / length / normalize: sums are taken left to right
+CLR_FN float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+CLR_FN float dot(vec2 a, vec2 b) { return a.x * b.x + a.y * b.y; }
+CLR_FN float dot(vec4 a, vec4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+CLR_FN vec3 cross(vec3 a, vec3 b) {
+    return make_vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+CLR_FN float length(vec3 a) { return sqrtf(dot(a, a)); }
+CLR_FN float length(vec4 a) { return sqrtf(dot(a, a)); }
+CLR_FN vec3 normalize(vec3 a) { return a / length(a); }
+#define fast_normalize normalize
+#define native_sqrt sqrtf
+
+// ---- interval arithmetic (static.cl:4-61); an interval is (x = begin, y = end)
+typedef vec2 ia_type;
+#define ia_new(b, e) make_vec2(b, e)
+#define ia_new_exact(ex) make_vec2(ex, ex)
+#define ia_begin(a) ((a).x)
+#define ia_end(a) ((a).y)
+#define ia_len(a) (ia_end(a) - ia_begin(a))
+#define ia_contains_zero(a) (ia_begin(a) <= 0.0f && ia_end(a) >= 0.0f)
+#define ia_center(a) ((ia_begin(a) + ia_end(a)) * 0.5f)
+#define ia_sub(a, b) ia_new(ia_begin(a) - ia_end(b), ia_end(a) - ia_begin(b))
+#define ia_neg(a) ia_new(-ia_end(a), -ia_begin(a))
+#define ia_mul_pos_exact(a, ex) ((a) * (float)(ex))
+#define ia_mul_neg_exact(a, ex) (ia_neg(a) * -(float)(ex))
+
+CLR_FN ia_type ia_abs(ia_type a) {
+    if (ia_begin(a) >= 0.0f) return a;
+    if (ia_end(a) <= 0.0f) return ia_neg(a);
+    return ia_new(0.0f, fmaxf(-ia_begin(a), ia_end(a)));
+}
+
+CLR_FN ia_type ia_mul(ia_type a, ia_type b) {
+    if (ia_contains_zero(a)) {
+        if (ia_contains_zero(b)) {
+            return ia_new(fminf(ia_begin(a) * ia_end(b), ia_begin(b) * ia_end(a)),
+                          fmaxf(ia_begin(a) * ia_begin(b), ia_end(a) * ia_end(b)));
+        }
+        ia_type tmp = b; b = a; a = tmp;
+    }
+    if (ia_end(a) < 0.0f) { a = ia_neg(a); b = ia_neg(b); }
+    // now ia_begin(a) > 0
+    if (ia_end(b) < 0.0f) return ia_new(ia_end(a) * ia_begin(b), ia_begin(a) * ia_end(b));
+    else if (ia_contains_zero(b)) return ia_new(ia_end(a) * ia_begin(b), ia_end(a) * ia_end(b));
+    else return a * b;
+}
+
+CLR_FN ia_type ia_pow2(ia_type a) { ia_type ab = ia_abs(a); return ab * ab; }
+CLR_FN ia_type ia_pow3(ia_type a) { return a * a * a; }
+CLR_FN ia_type ia_pow4(ia_type a) { ia_type a2 = ia_pow2(a); return a2 * a2; }
+
+// ---- affine helpers (static.cl:66-82): rows of the matrix in m[0..2].xyz, translation m[3].xyz
+CLR_FN vec3 apply_linear_transform(const float4* m, vec3 v) {
+    return make_vec3(dot(make_vec3(m[0]), v), dot(make_vec3(m[1]), v), dot(make_vec3(m[2]), v));
+}
+CLR_FN vec3 apply_transposed_linear_transform(const float4* m, vec3 v) {
+    return make_vec3(dot(make_vec3(m[0].x, m[1].x, m[2].x), v),
+                     dot(make_vec3(m[0].y, m[1].y, m[2].y), v),
+                     dot(make_vec3(m[0].z, m[1].z, m[2].z), v));
+}
+CLR_FN vec3 apply_affine_transform(const float4* m, vec3 v) {
+    return apply_linear_transform(m, v) + make_vec3(m[3]);
+}
+
+// ---- quaternions (static.cl:87-101): x = real part
+CLR_FN vec4 quaternion_mult(vec4 q1, vec4 q2) {
+    vec3 v1 = make_vec3(q1.y, q1.z, q1.w), v2 = make_vec3(q2.y, q2.z, q2.w);
+    vec3 im = q1.x * v2 + q2.x * v1 + cross(v1, v2);
+    return make_vec4(q1.x * q2.x - dot(v1, v2), im.x, im.y, im.z);
+}
+CLR_FN vec4 quaternion_square(vec4 q) {
+    vec3 v = make_vec3(q.y, q.z, q.w);
+    float two_r = 2 * q.x;
+    return make_vec4(q.x * q.x - dot(v, v), two_r * q.y, two_r * q.z, two_r * q.w);
+}

@@ -1,0 +1,163 @@
+{#- Scaffolding shared by all shape templates: function signatures, parameter fetch and the
+    three per-class step functions (closest hit, shadow test, normal).  Counterpart of the
+    reference's tracer.cl (/root/reference/cl_templates/tracer.cl:2-284); there the three
+    steps are separate kernels launched per object / per class, here they are __device__
+    functions inlined into the fused bounce kernel (main.hip). -#}
+
+### macro normal_function_base(obj)
+{#- exterior normal at a surface point, in tracer coordinates #}
+CLR_FN void {{ obj.normal_function_name }}(
+        const vec3 pos,              // a point on the surface
+        const uint subobject,        // sub-object number computed by the tracer
+        vec3 *p_normal               // [out]
+        {{ obj.parameter_declaration_string() }}) {
+{{ caller() }}
+}
+### endmacro
+
+### macro tracer_function_base(obj)
+{#- distance to the nearest valid intersection of a ray with the shape, tracer coordinates #}
+CLR_FN void {{ obj.tracer_function_name }}(
+        const vec3 origin,
+        const vec3 ray,
+        const float t_limit,   // upper bound for the distance
+        float *t_hit,      // [out] stays 0 when there is no hit
+        uint *p_subobject,           // [in/out] e.g. which face
+        bool inside,                 // ray travels inside this object
+        bool on_surface             // ray starts on this object's surface
+        {{ obj.parameter_declaration_string() }}) {
+{{ caller() }}
+}
+### endmacro
+
+### macro tracer_component_function_base(obj)
+CLR_FN void {{ obj.tracer_function_name }}(
+        const vec3 origin,
+        const vec3 ray,
+        float *t_enter,         // [in/out] interval of the ray inside the component
+        float *t_exit,
+        uint *p_subobject,
+        bool inside
+        {{ obj.parameter_declaration_string() }}) {
+{{ caller() }}
+}
+### endmacro
+
+{#- actual arguments for the declared parameters of obj, read from the parameter table P #}
+### macro tracer_params(obj)
+    ### if obj.has_data()
+        , vector_data + clr_data_offsets[2*(object_id-1)]
+        , integer_data + clr_data_offsets[2*(object_id-1)+1]
+    ### endif
+    ### for cl_type in obj.parameter_types()
+        ### if cl_type == 'float3'
+        , make_vec3(P[{{ loop.index0 }}])
+        ### elif cl_type == 'int'
+        , __float_as_int(P[{{ loop.index0 }}].x)
+        ### else
+        , P[{{ loop.index0 }}].x
+        ### endif
+    ### endfor
+### endmacro
+
+### macro tracer_kernel(obj)
+// closest-hit step for one object of this class (tracer.cl:72-141)
+CLR_FN void {{ obj.tracer_kernel_name }}(
+    const vec3 pos, const vec3 ray, float &isec_dist, uint &whichobject, uint &which_subobject,
+    const uint last_whichobject, const uint last_which_subobject, const uint inside,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
+    const int object_id, const float4 *P)
+{
+    const bool within = inside == (uint)object_id,
+               on_surface = last_whichobject == (uint)object_id;
+    ### if obj.convex
+    if (!on_surface || within) {
+    ### endif
+        float new_isec_dist = 0;
+        uint cur_subobject = last_which_subobject;
+        const float4 *p_inverse_affine = P + {{ obj.parameter_types()|length }};
+
+        const vec3 local_pos = apply_affine_transform(p_inverse_affine, pos);
+        const vec3 local_ray = apply_linear_transform(p_inverse_affine, ray);
+        const float stretch = length(local_ray);
+
+        {{ obj.tracer_function_name }}(
+            local_pos, local_ray/stretch, isec_dist*stretch, &new_isec_dist, &cur_subobject,
+            within, on_surface
+            {{ tracer_params(obj) }}
+        );
+
+        if (new_isec_dist > 0) {
+            new_isec_dist /= stretch;
+            if (new_isec_dist < isec_dist) {
+                isec_dist = new_isec_dist;
+                which_subobject = cur_subobject;
+                whichobject = object_id;
+            }
+        }
+    ### if obj.convex
+    }
+    ### endif
+}
+### endmacro
+
+### macro shadow_kernel(obj)
+// visibility step towards the light point for one object of this class (tracer.cl:143-221);
+// `ray`/`isec_dist` = unit direction and distance to the light point, computed by the caller
+CLR_FN void {{ obj.shadow_kernel_name }}(
+    const vec3 pos, const vec3 ray, const float isec_dist,
+    const uint whichobject, const uint which_subobject, const uint inside, float &shadow_mask,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
+    const int object_id, const float4 *P)
+{
+    uint subobject = which_subobject;
+    const bool within = inside == (uint)object_id,
+               on_surface = whichobject == (uint)object_id;
+    float new_isec_dist = 0;
+    ### if obj.convex
+    if (!on_surface || within) {
+    ### endif
+        const float4 *p_inverse_affine = P + {{ obj.parameter_types()|length }};
+        const vec3 local_pos = apply_affine_transform(p_inverse_affine, pos);
+        const vec3 local_ray = apply_linear_transform(p_inverse_affine, ray);
+        const float stretch = length(local_ray);
+
+        {{ obj.tracer_function_name }}(
+            local_pos, local_ray/stretch, isec_dist*stretch, &new_isec_dist, &subobject,
+            within, on_surface
+            {{ tracer_params(obj) }}
+        );
+
+        if (new_isec_dist > 0) {
+            new_isec_dist /= stretch;
+            if (new_isec_dist < isec_dist) shadow_mask = 0.0f;
+        }
+    ### if obj.convex
+    }
+    ### endif
+}
+### endmacro
+
+### macro normal_kernel(obj)
+// world-space normal at `pos` on object `object_id` of this class (tracer.cl:223-284)
+CLR_FN vec3 {{ obj.normal_kernel_name }}(
+    const vec3 pos, const vec3 ray, const uint subobject, const uint inside,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
+    const int object_id, const float4 *P)
+{
+    const float4 *p_inverse_affine = P + {{ obj.parameter_types()|length }};
+    const vec3 local_pos = apply_affine_transform(p_inverse_affine, pos);
+    vec3 normal = make_vec3(0.0f, 0.0f, 0.0f);
+    {{ obj.normal_function_name }}(
+        local_pos, subobject, &normal
+        {{ tracer_params(obj) }}
+    );
+    normal = normalize(apply_transposed_linear_transform(p_inverse_affine, normal));
+    ### if obj.auto_flip_normal
+        if (dot(normal, ray) > 0) normal = -normal;
+    ### else
+        if (inside == (uint)object_id) normal = -normal;
+    ### endif
+    return normal;
+}
+### endmacro

@@ -1,0 +1,173 @@
+"""Octree over a TriangleMesh (reference objects/octree.py:4-233).
+
+``build()`` restates the reference's breadth-first construction (bounding-sphere and
+face-plane overlap test per node, leaf when few "small" faces remain or at max depth) with a
+per-node vectorised test instead of the reference's dense (nodes x faces) matrices, and
+``get_data()`` emits the reference's integer stream (faces, then post-order node payloads,
+root header last).  Face indices are tracked explicitly, so the reference's latent
+``active_faces`` indexing hazard (octree.py:215-231) is not reproduced; results coincide
+whenever no face drops out of the active set, e.g. the scene-test cube.
+"""
+import numpy
+from ..tracer import Tracer
+
+EMPTY_HEADER = [0x100, -99999]
+
+
+class Octree(Tracer):
+
+    MAX_DEPTH = 7
+
+    def __init__(self, triangle_mesh, max_depth=3, max_faces_per_leaf=5):
+        mesh_pose = triangle_mesh.coordinates
+        self.triangle_mesh = triangle_mesh
+        Tracer.__init__(self)          # assigns an identity pose through the setter below
+        self.coordinates = mesh_pose   # ... so put the mesh's own pose back
+        self.max_depth = max_depth
+        self.max_faces_per_leaf = max_faces_per_leaf
+        if self.max_depth >= self.__class__.MAX_DEPTH:
+            raise RuntimeError("max_depth >= MAX_DEPTH")
+        self.build()
+
+    @property
+    def auto_flip_normal(self):
+        return self.triangle_mesh.auto_flip_normal
+
+    @property
+    def coordinates(self):
+        return self.triangle_mesh.coordinates
+
+    @coordinates.setter
+    def coordinates(self, value):
+        # Tracer.__init__ assigns a fresh identity before the mesh pose is restored
+        self.triangle_mesh.coordinates = value
+
+    class Node:
+        child_order = [[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)]
+
+        def __init__(self, origin, size, parent=None):
+            self.children = []
+            self.faces = []
+            self.origin = origin
+            self.size = size
+            self.parent = parent
+
+        def is_empty(self):
+            return len(self.faces) == 0
+
+        def is_leaf(self):
+            return len(self.children) == 0
+
+        @property
+        def center(self):
+            return numpy.array([self.size * 0.5] * 3) + self.origin
+
+        def get_bounding_sphere(self):
+            return self.center, numpy.sqrt(3) * self.size * 0.5
+
+        def get_children(self):
+            if not self.children:
+                for xyz in Octree.Node.child_order:
+                    self.children.append(Octree.Node(
+                        self.origin + numpy.array(xyz) * 0.5 * self.size, self.size * 0.5, self))
+            return self.children
+
+    def build(self):
+        mesh = self.triangle_mesh
+        self.center, self.size = mesh.get_bounding_cube()
+        self.center = numpy.asarray(self.center, dtype=numpy.float64)
+        self.size = float(self.size) * 1.01
+        self.origin = numpy.array(self.center) - numpy.array([self.size * 0.5] * 3)
+        self.root = Octree.Node(self.origin, self.size)
+
+        face_centers, face_radii = face_bounding_spheres(mesh.vertices, mesh.faces)
+        face_normals, face_h = face_planes(mesh.vertices, mesh.faces)
+
+        self.leaves = []
+        depth = 0
+        active_nodes = [self.root]
+        active_faces = numpy.arange(mesh.n_faces)
+        while active_nodes:
+            touched = numpy.zeros(len(active_faces), dtype=bool)
+            for node in active_nodes:
+                c, r = node.get_bounding_sphere()
+                gap = numpy.sqrt(numpy.sum((c[None, :] - face_centers[active_faces]) ** 2, 1))
+                gap = gap - r - face_radii[active_faces]
+                plane_gap = numpy.abs(face_normals[active_faces] @ c - face_h[active_faces]) - r
+                hit = numpy.maximum(gap, plane_gap) < 0
+                node.faces.extend(int(f) for f in active_faces[hit])
+                touched |= hit
+            active_faces = active_faces[touched]
+
+            next_nodes = []
+            for node in active_nodes:
+                n_small = sum(1 for f in node.faces if face_radii[f] < node.size * 0.5)
+                if n_small <= self.max_faces_per_leaf or depth == self.max_depth:
+                    self.leaves.append(node)
+                else:
+                    node.faces = []
+                    next_nodes += node.get_children()
+            active_nodes = next_nodes
+            depth += 1
+
+    def get_data(self):
+        """Serialise: mesh faces (3N ints) followed by the node stream."""
+        def write_node(node, stream):
+            child_mask = 0
+            if node.is_leaf():
+                if node.is_empty():
+                    return list(EMPTY_HEADER)
+                payload = [len(node.faces)] + list(node.faces)
+            else:
+                payload = []
+                for i, child in enumerate(node.children):
+                    if child.is_empty() and child.is_leaf():
+                        header = list(EMPTY_HEADER)
+                    else:
+                        child_mask |= 1 << i
+                        header = write_node(child, stream)
+                    payload += header
+                if child_mask == 0:
+                    return list(EMPTY_HEADER)
+            offset = len(stream)
+            stream.extend(payload)
+            return [child_mask, offset]
+
+        stream = []
+        root_header = write_node(self.root, stream)
+        self.root_data_offset = len(stream)
+        stream.extend(root_header)
+
+        data = self.triangle_mesh.get_data()
+        data['integer'] = numpy.concatenate(
+            [numpy.ravel(data['integer']), numpy.array(stream, dtype=numpy.int64)]).astype(numpy.int32)
+        return data
+
+    @property
+    def total_faces(self):
+        return len(self.triangle_mesh.faces)
+
+    def parameter_declarations(self):
+        return ['int n_vertices', 'int n_triangles', 'int root_data_offset',
+                'int face_data_length', 'float3 root_origin', 'float root_size']
+
+    def parameter_values(self):
+        if not hasattr(self, 'root_data_offset'):
+            self.get_data()
+        return [self.triangle_mesh.n_vertices, self.triangle_mesh.n_faces,
+                self.root_data_offset, self.total_faces * 3, self.root.origin, self.root.size]
+
+
+def face_bounding_spheres(vertices, faces):
+    tri = vertices[faces].astype(numpy.float64)   # (F, 3 corners, 3)
+    centers = tri.mean(axis=1)
+    radii = numpy.sqrt(numpy.max(numpy.sum((tri - centers[:, None, :]) ** 2, axis=2), axis=1))
+    return centers, radii
+
+
+def face_planes(vertices, faces):
+    v = vertices.astype(numpy.float64)
+    p0 = v[faces[:, 0]]
+    normals = numpy.cross(v[faces[:, 1]] - p0, v[faces[:, 2]] - p0)
+    normals = normals / numpy.sqrt(numpy.sum(normals ** 2, 1))[:, None]
+    return normals, numpy.sum(p0 * normals, 1)

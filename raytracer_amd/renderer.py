@@ -1,0 +1,337 @@
+"""Render controller: packs the scene for the device, generates the random tape and drives
+the fused render kernel.
+
+Host-side mirror of the reference's ``Renderer`` (/root/reference/renderer.py:12-518) with
+the same public surface (``Renderer(scene, args)``, ``render_sample(i)``, ``get_image()``,
+``rays_per_sample()``, ``acc``).  What the reference does with ~28 blocking kernel launches
+per bounce, this class does with one launch per *batch of passes*
+(``render_samples(first, count)``): the per-pass camera sample and the per-bounce random
+numbers (which the reference draws on the host and broadcasts to every pixel) are drawn in
+the same order, stored in a tape and replayed by the device.
+"""
+import itertools
+import math
+import numpy as np
+
+from . import camera, utils
+from .hip_compiler import Compiler, PARITY_OPTIONS
+from .accelerator import Accelerator, RenderArgs
+
+PASS_RECORD = 6      # float4 per pass in the tape
+BOUNCE_RECORD = 5    # float4 per path segment in the tape
+DEBUG_RECORD = 6     # float4 per (segment, pixel) in the debug dump
+
+
+class Renderer:
+
+    def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
+                 device_index=0):
+        self.scene = scene
+        self.shader = scene.shader(scene)
+        self.rng = np.random.RandomState(seed)
+
+        self._group_objects()
+        self._init_lights()
+        self._collect_tracer_data()
+        self._init_misc()
+        self._init_camera_and_image()
+        self._init_materials()
+
+        self.program_code = Compiler(self).make_program()
+        self.build_options = list(build_options if build_options is not None else PARITY_OPTIONS)
+        extra = getattr(args, 'cl_build_options', None)
+        if extra:
+            self.build_options += extra.split()
+        self.regenerate = True
+        self.acc = None
+        if device:
+            self.connect(device_index)
+
+    # ------------------------------------------------------------------ scene preparation
+    def _group_objects(self):
+        """Sort objects by step-function name (stable) and number them from 1
+        (reference renderer.py:51-74)."""
+        key = lambda obj: obj.tracer.tracer_kernel_name
+        self.scene.objects.sort(key=key)
+        self.object_groups = []
+        offset = 0
+        for _, members in itertools.groupby(self.scene.objects, key=key):
+            members = list(members)
+            self.object_groups.append((members[0].tracer, len(members), offset))
+            offset += len(members)
+        self.root_object_id = 0
+        for i, obj in enumerate(self.scene.objects):
+            if self.scene.root_object is obj:
+                self.root_object_id = i + 1
+
+    def _init_lights(self):
+        self.bidirectional_light_ids = [i for i, obj in enumerate(self.scene.objects)
+                                        if obj.bidirectional_light]
+        self.bidirectional = len(self.bidirectional_light_ids) > 0
+
+    def _collect_tracer_data(self):
+        """Pack per-object parameters and mesh data (role of reference renderer.py:121-241).
+
+        Layout: `param_table` holds one float4 slot per declared parameter of an object
+        (float3 in xyz, float or bit-cast int in x) followed by four slots with the rows
+        and the translation of the INVERSE of global_to_tracer_coordinate_transform().
+        Objects of one group are contiguous with a common stride, so a step function finds
+        its slots at group_base + i * group_stride.  Mesh data go to `vector_data` (float4)
+        and `integer_data` (int32) with per-object offsets in `data_offsets`.
+        """
+        slots, vectors, integers, data_offsets = [], [], [], []
+        n_vec = n_int = 0
+        self.object_param_base = []
+        for obj in self.scene.objects:
+            tracer = obj.tracer
+            data_offsets += [n_vec, n_int]
+            if tracer.has_data():
+                data = tracer.get_data()
+                vec = np.asarray(data['vector'], dtype=np.float32)
+                if vec.ndim != 2 or vec.shape[1] != 3:
+                    raise RuntimeError('invalid vector data shape')
+                vectors.append(vec)
+                n_vec += vec.shape[0]
+                ints = np.ravel(data['integer']).astype(np.int32)
+                integers.append(ints)
+                n_int += ints.size
+            self.object_param_base.append(len(slots))
+            for cl_type, value in zip(tracer.parameter_types(), tracer.parameter_values()):
+                slot = np.zeros(4, dtype=np.float32)
+                if cl_type == 'float3':
+                    slot[:3] = np.ravel(value)
+                elif cl_type == 'int':
+                    slot[:1] = np.array([value], dtype=np.int32).view(np.float32)
+                elif cl_type == 'float':
+                    slot[0] = value
+                else:
+                    raise RuntimeError('unsupported parameter type %s' % cl_type)
+                slots.append(slot)
+            inverse = tracer.global_to_tracer_coordinate_transform().inverse()
+            for row in (inverse.linear[0, :], inverse.linear[1, :], inverse.linear[2, :],
+                        inverse.translation):
+                slot = np.zeros(4, dtype=np.float32)
+                slot[:3] = row
+                slots.append(slot)
+            tracer.param_slots = len(slots) - self.object_param_base[-1]
+
+        self.param_table = np.array(slots, dtype=np.float32).reshape(-1, 4)
+        self.n_param_slots = self.param_table.shape[0]
+        self.data_offsets = np.array(data_offsets, dtype=np.int32)
+        self.vector_data = (Accelerator.host_vec3_array(np.vstack(vectors)) if vectors
+                            else np.zeros((1, 4), dtype=np.float32))
+        self.integer_data = (np.concatenate(integers) if integers else np.zeros(1, dtype=np.int32))
+
+        self.group_param_base, self.group_param_stride = [], []
+        for tracer, count, offset in self.object_groups:
+            strides = {self.scene.objects[offset + i].tracer.param_slots for i in range(count)}
+            assert len(strides) == 1, "objects of one group must share a parameter layout"
+            self.group_param_base.append(self.object_param_base[offset])
+            self.group_param_stride.append(strides.pop())
+
+    def _init_misc(self):
+        # consumes the RNG exactly like the reference (renderer.py:84-85)
+        self.qdirs = camera.quasi_random_direction_sample(self.scene.samples_per_pixel)
+        self.qdirs = self.rng.permutation(self.qdirs)
+
+    def _init_camera_and_image(self):
+        scene = self.scene
+        cam = scene.get_camera_rays()
+        self.rotmat = scene.get_camera_rotmat()
+        fovx_rad = scene.camera_fov / 180.0 * np.pi
+        self.pixel_angle = fovx_rad / scene.image.size[0]
+        self.img_shape = tuple(scene.image.size[::-1])          # (H, W)
+        self.n_pixels = self.img_shape[0] * self.img_shape[1]
+        self.image_order = self.get_image_order()
+        self.host_cam = Accelerator.host_vec3_array(
+            cam[self.image_order[:, 0], self.image_order[:, 1], 0:3])
+
+    def _init_materials(self):
+        if self.shader.rgb:
+            self.material_colors, self.material_scalars = self.shader.host_material_tables()
+        else:
+            self.shader.prepare_host_tables()
+
+    def get_image_order(self):
+        """Ray index -> (row, col): 8-row x 4-column blocks, column blocks outermost
+        (reference renderer.py:435-456; its `width` is the image height)."""
+        rows, cols = self.img_shape
+        block_r, block_c = 8, 4
+        if rows % block_r == 0 and cols % block_c == 0:
+            k = np.arange(rows * cols)
+            in_r = k % block_r
+            in_c = (k // block_r) % block_c
+            blk_r = (k // (block_r * block_c)) % (rows // block_r)
+            blk_c = k // (block_r * block_c * (rows // block_r))
+            return np.column_stack((in_r + blk_r * block_r, in_c + blk_c * block_c))
+        print("WARNING: image size should be (%d*x, %d*y)" % (block_c, block_r))
+        r, c = np.meshgrid(np.arange(rows), np.arange(cols), indexing='ij')
+        return np.column_stack((r.ravel(), c.ravel()))
+
+    # ------------------------------------------------------------------ random tape
+    def new_camera_sample(self):
+        """Sub-pixel jitter and depth-of-field offset of one pass (reference renderer.py:251-291)."""
+        scene = self.scene
+        sx = np.float32(self.rng.rand())
+        sy = np.float32(self.rng.rand())
+        if scene.tent_filter:
+            def tent(x):
+                x *= 2
+                return np.sqrt(x) - 1 if x < 1 else 1 - np.sqrt(2 - x)
+            sx, sy = tent(sx), tent(sy)
+        overlap = 0.0
+        thetax = (sx - 0.5) * self.pixel_angle * (1.0 + overlap)
+        thetay = (sy - 0.5) * self.pixel_angle * (1.0 + overlap)
+        dofx, dofy = camera.random_dof_sample(self.rng)
+        dof_pos = (dofx * self.rotmat[:, 0] + dofy * self.rotmat[:, 1]) * scene.camera_dof_fstop
+        tilt = camera.rotmat_tilt_camera(thetax, thetay)
+        mat4 = np.zeros((4, 4))
+        mat4[0:3, 0:3] = np.dot(np.dot(self.rotmat, tilt), self.rotmat.transpose())
+        mat4[3, 0:3] = dof_pos
+        mat4[3, 3] = scene.camera_sharp_distance
+        return np.asarray(scene.camera_position) + dof_pos, mat4
+
+    def get_light_point(self):
+        ids = self.bidirectional_light_ids
+        light_id = ids[self.rng.randint(len(ids))]
+        tracer = self.scene.objects[light_id].tracer
+        return ((light_id, tracer.surface_area()) + tracer.random_surface_point_and_normal(self.rng)
+                + tracer.center_and_min_sampling_distance())
+
+    def make_tape(self, first_pass, n_passes):
+        """Draw the random numbers of `n_passes` passes in the reference's order (SURVEY
+        Appendix B) and lay them out for the device."""
+        scene = self.scene
+        max_bounces = scene.max_bounces
+        passes = np.zeros((n_passes, PASS_RECORD, 4), dtype=np.float32)
+        bounces = np.zeros((n_passes, max_bounces, BOUNCE_RECORD, 4), dtype=np.float32)
+        rows = None
+        if not self.shader.rgb:
+            rows = np.zeros((n_passes, self.shader.host_mat_y.shape[0]), dtype=np.float32)
+        for j in range(n_passes):
+            cam_origin, mat4 = self.new_camera_sample()
+            passes[j, 0:4, :] = mat4
+            passes[j, 4, 0:3] = cam_origin
+            passes[j, 4, 3] = 1.0
+            passes[j, 5, 0:3] = 1.0
+            if rows is not None:
+                inv_pdf, rows[j], cmask = self.shader.sample_wavelength(self.rng.random_sample())
+                passes[j, 4, 3] = inv_pdf
+                passes[j, 5, 0:3] = cmask
+            for b in range(max_bounces):
+                is_last = b == max_bounces - 1
+                rec = bounces[j, b]
+                if self.bidirectional:
+                    light_id0, area, point, normal, center, min_dist = self.get_light_point()
+                    rec[2, 0:3], rec[2, 3] = point, area
+                    rec[3, 0:3], rec[3, 3] = normal, min_dist
+                    rec[4, 0:3] = center
+                    rec[4, 3:4] = np.array([0 if is_last else light_id0 + 1], dtype=np.int32).view(np.float32)
+                if scene.quasirandom and b == 1:
+                    rec[0, 0:3] = self.qdirs[first_pass + j, :]
+                else:
+                    rec[0, 0:3] = utils.normalize(self.rng.normal(0, 1, (3,)))
+                rec[0, 3] = np.float32(self.rng.rand())
+                rec[1, 0:3] = self.rng.normal(0, 1, (3,))
+                if not is_last:
+                    rec[1, 3] = np.float32(self.rng.rand())
+        return passes, bounces, rows
+
+    # ------------------------------------------------------------------ device
+    def connect(self, device_index=0):
+        """Create the device context, upload the scene and build the program."""
+        acc = self.acc = Accelerator(device_index)
+        self.cam = acc.to_device(self.host_cam)
+        self.img = acc.new_vec3_array((self.n_pixels,))
+        self.dev_vector_data = acc.to_device(self.vector_data)
+        self.dev_integer_data = acc.to_device(self.integer_data)
+        self.prog = acc.build_program(self.program_code, self.build_options)
+        if self.n_param_slots:
+            acc.set_global('clr_params', self.param_table)
+        acc.set_global('clr_data_offsets', self.data_offsets)
+        if self.shader.rgb:
+            acc.set_global('clr_material_colors', self.material_colors)
+            acc.set_global('clr_material_scalars', self.material_scalars)
+        self._tape_capacity = 0
+
+    def _upload_tape(self, tape):
+        passes, bounces, rows = tape
+        acc = self.acc
+        n = passes.shape[0]
+        if n > self._tape_capacity:
+            self.dev_pass_tape = acc.new_array((n,) + passes.shape[1:], np.float32)
+            self.dev_bounce_tape = acc.new_array((n,) + bounces.shape[1:], np.float32)
+            self.dev_rows = (acc.new_array((n, rows.shape[1]), np.float32) if rows is not None else None)
+            self._tape_capacity = n
+        self.dev_pass_tape[:n].set(passes)
+        self.dev_bounce_tape[:n].set(bounces)
+        if rows is not None:
+            self.dev_rows[:n].set(rows)
+
+    def render_tape(self, tape, debug=False, stream=None, timed=True):
+        """Render the passes described by `tape` and add them to the image accumulator.
+        Returns (kernel milliseconds, debug dump or None)."""
+        n = tape[0].shape[0]
+        self._upload_tape(tape)
+        dump = None
+        if debug:
+            dump = self.acc.new_array((self.scene.max_bounces, self.n_pixels, DEBUG_RECORD, 4),
+                                      np.float32, zeros=True)
+        args = RenderArgs(
+            img=self.img.ptr, cam=self.cam.ptr, pass_tape=self.dev_pass_tape.ptr,
+            bounce_tape=self.dev_bounce_tape.ptr,
+            material_rows=self.dev_rows.ptr if self.dev_rows is not None else None,
+            vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
+            n_pixels=self.n_pixels, n_passes=n, regenerate=int(self.regenerate),
+            debug_dump=dump.ptr if dump is not None else None)
+        ms = self.acc.render_passes(args, stream=stream, timed=timed)
+        return ms, (dump.get() if dump is not None else None)
+
+    def render_samples(self, first_pass, n_passes):
+        """Render passes [first_pass, first_pass + n_passes) with one kernel launch."""
+        ms, _ = self.render_tape(self.make_tape(first_pass, n_passes))
+        return ms
+
+    def render_sample(self, sample_index):
+        """One sample pass (reference renderer.py:293-324); returns the last path index."""
+        self.render_samples(sample_index, 1)
+        return self.scene.max_bounces - 1
+
+    def first_hit(self, tape=None):
+        """Object / sub-object ids, hit distance and normal of the primary rays, image-shaped."""
+        if tape is None:
+            tape = self.make_tape(0, 1)
+        self._upload_tape(tape)
+        acc = self.acc
+        ids = acc.new_array((self.n_pixels, 2), np.int32, zeros=True)
+        t = acc.new_array((self.n_pixels,), np.float32, zeros=True)
+        normal = acc.new_array((self.n_pixels, 4), np.float32, zeros=True)
+        import ctypes
+        from .accelerator import _check
+        _check(acc.lib.clr_first_hit(acc.prog, self.cam.ptr, self.dev_pass_tape.ptr,
+                                     self.dev_vector_data.ptr, self.dev_integer_data.ptr,
+                                     self.n_pixels, ids.ptr, t.ptr, normal.ptr, None))
+        acc.finish()
+        return ids.get(), t.get(), normal.get()[:, :3]
+
+    # ------------------------------------------------------------------ results
+    def unpermute(self, per_ray):
+        """(n_pixels, C) in ray order -> (H, W, C) image."""
+        out = np.empty(self.img_shape + per_ray.shape[1:], dtype=per_ray.dtype)
+        out[self.image_order[:, 0], self.image_order[:, 1]] = per_ray
+        return out
+
+    def get_image(self):
+        """Sum over all passes so far, (H, W, 3) (reference renderer.py:24-28)."""
+        return self.unpermute(self.img.get().astype(np.float32)[:, 0:3]).astype(np.float64)
+
+    def rays_per_sample(self):
+        return self.n_pixels
+
+    @property
+    def warp_size(self):
+        return 64
+
+    @property
+    def log_warp_size(self):
+        return int(round(math.log(self.warp_size, 2)))
