@@ -1,0 +1,1020 @@
+/* clray_oracle.c - CPU restatement of the reference path tracer (TEST INFRASTRUCTURE ONLY;
+ * see clray_oracle.h).  Every function names the reference code it follows; the arithmetic
+ * keeps the reference's order of operations in IEEE binary32 (compile with
+ * -ffp-contract=off, no fast-math) so that the HIP back end can be compared bit for bit.
+ *
+ * Structure: one fused loop per pixel over passes and path segments, OpenMP over pixels.
+ * The reference sweeps all rays once per object / stage instead (renderer.py:326-433); per
+ * ray the sequence of operations is the same.
+ *
+ * ORC_COUNT_FLOPS: when defined, FL(n) tallies algorithmic FP32 operations (1 per add, sub,
+ * mul, div, sqrt, compare, min/max, negate-free; transcendental = 1), see DESIGN.md.
+ */
+#include "clray_oracle.h"
+#include "clray_oracle_gen.h"
+
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned int uint;
+typedef struct { float x, y, z; } vec3;
+typedef struct { float x, y; } vec2;
+typedef struct { float x, y, z, w; } vec4;
+
+#ifdef ORC_COUNT_FLOPS
+static __thread double orc_flops;
+#define FL(n) (orc_flops += (n))
+#else
+#define FL(n) ((void)0)
+#endif
+
+#define PI_F 3.14159274101257324f
+
+/* ---- vector algebra, same definitions as hip_templates/static.hip ---- */
+static inline vec3 v3(float x, float y, float z) { vec3 v = {x, y, z}; return v; }
+static inline vec3 v3p(const float *p) { return v3(p[0], p[1], p[2]); }
+static inline vec3 add3(vec3 a, vec3 b) { FL(3); return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline vec3 sub3(vec3 a, vec3 b) { FL(3); return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline vec3 mul3(vec3 a, vec3 b) { FL(3); return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline vec3 neg3(vec3 a) { return v3(-a.x, -a.y, -a.z); }
+static inline vec3 scale3(vec3 a, float s) { FL(3); return v3(a.x * s, a.y * s, a.z * s); }
+static inline vec3 lscale3(float s, vec3 a) { FL(3); return v3(s * a.x, s * a.y, s * a.z); }
+static inline vec3 div3(vec3 a, float s) { FL(3); return v3(a.x / s, a.y / s, a.z / s); }
+static inline float dot3(vec3 a, vec3 b) { FL(5); return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float dot2(vec2 a, vec2 b) { FL(3); return a.x * b.x + a.y * b.y; }
+static inline float dot4(vec4 a, vec4 b) { FL(7); return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+static inline vec3 cross3(vec3 a, vec3 b) {
+    FL(9);
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float length3(vec3 a) { FL(1); return sqrtf(dot3(a, a)); }
+static inline vec3 normalize3(vec3 a) { return div3(a, length3(a)); }
+
+/* static.cl:66-82 */
+static inline vec3 linear_tf(const float *m, vec3 v) {
+    return v3(dot3(v3p(m), v), dot3(v3p(m + 3), v), dot3(v3p(m + 6), v));
+}
+static inline vec3 transposed_linear_tf(const float *m, vec3 v) {
+    return v3(dot3(v3(m[0], m[3], m[6]), v), dot3(v3(m[1], m[4], m[7]), v), dot3(v3(m[2], m[5], m[8]), v));
+}
+static inline vec3 affine_tf(const float *m, vec3 v) { return add3(linear_tf(m, v), v3p(m + 9)); }
+
+/* ====================================================================================
+ * shapes
+ * ==================================================================================== */
+
+/* objects/Sphere.cl:3-30 */
+static void sphere_tracer(vec3 origin, vec3 ray, float *p_new, int inside) {
+    float dotp = -dot3(ray, origin);
+    float psq = dot3(origin, origin);
+    FL(2);
+    if (dotp <= 0 && !inside) return;
+    float discr = dotp * dotp - psq + 1.0f;
+    FL(4);
+    if (discr < 0) return;
+    float sqrdiscr = sqrtf(discr);
+    float dist;
+    FL(3);
+    if (inside) dist = dotp + sqrdiscr;
+    else dist = dotp - sqrdiscr;
+    if (dist <= 0) return;
+    *p_new = dist;
+}
+
+/* objects/HalfSpace.cl:3-10 */
+static void halfspace_tracer(vec3 origin, vec3 ray, float *p_new) {
+    const float dist = -origin.x / ray.x;
+    FL(2);
+    if (dist > 0) *p_new = dist;
+}
+
+/* ---- convex components: clip [begin, end] --------------------------------------------- */
+
+/* objects/SphereComponent.cl:3-26 */
+static void c_sphere(vec3 origin, vec3 ray, float *b, float *e, float R) {
+    float dotp = -dot3(ray, origin);
+    float psq = dot3(origin, origin);
+    float discr = dotp * dotp - psq + R * R;
+    FL(5);
+    if (discr < 0) { *b = 1; *e = 0; return; }
+    float sq = sqrtf(discr);
+    FL(3);
+    *b = dotp - sq;
+    *e = dotp + sq;
+}
+
+/* objects/HalfSpaceComponent.cl:3-15 */
+static void c_halfspace(vec3 origin, vec3 ray, float *b, float *e, uint *sub, vec3 normal, float h) {
+    float slope = dot3(ray, normal);
+    float dist = dot3(neg3(origin), normal) + h;
+    dist = dist / slope;
+    FL(3);
+    if (slope < 0) *b = dist;
+    else *e = dist;
+    *sub = 0;
+}
+
+/* objects/LayerComponent.cl:3-24 and ZLayerComponent.cl:3-24 */
+static void c_layer(vec3 origin, vec3 ray, float *b, float *e, uint *sub, int inside,
+                    vec3 normal, float h, int z_variant) {
+    float slope, base, d1, d2;
+    if (z_variant) { slope = ray.z; base = -origin.z; h = 1.0f; }
+    else { slope = dot3(ray, normal); base = dot3(neg3(origin), normal); }
+    if (slope > 0) { d1 = base; d2 = d1 + h; }
+    else { d2 = base; d1 = d2 + h; }
+    FL(5);
+    if ((slope > 0) == (inside != 0)) *sub = 1;
+    else *sub = 0;
+    *b = d1 / slope;
+    *e = d2 / slope;
+}
+
+/* objects/CylinderComponent.cl:3-34 and ZCylinderComponent.cl:3-32 */
+static void c_cylinder(vec3 origin, vec3 ray, float *b, float *e, vec3 axis, float R, int z_variant) {
+    float dotp, perp2, ray_perp2, rr;
+    if (z_variant) {
+        vec2 perp = {origin.x, origin.y}, ray_perp = {ray.x, ray.y};
+        dotp = dot2(ray_perp, perp);
+        perp2 = dot2(perp, perp);
+        ray_perp2 = dot2(ray_perp, ray_perp);
+        rr = 1.0f;
+    } else {
+        float z0 = dot3(origin, axis), zslope = dot3(ray, axis);
+        vec3 perp = sub3(origin, lscale3(z0, axis));
+        vec3 ray_perp = sub3(ray, lscale3(zslope, axis));
+        dotp = dot3(ray_perp, perp);
+        perp2 = dot3(perp, perp);
+        ray_perp2 = dot3(ray_perp, ray_perp);
+        rr = R * R;
+        FL(1);
+    }
+    float discr = dotp * dotp - ray_perp2 * (perp2 - rr);
+    FL(5);
+    if (discr < 0) { *b = 1; *e = 0; return; }
+    float sq = sqrtf(discr);
+    float d1 = -dotp - sq;
+    FL(6);
+    *b = d1 / ray_perp2;
+    *e = (d1 + 2 * sq) / ray_perp2;
+}
+
+/* objects/ConeComponent.cl:3-59 and ZConeComponent.cl:3-56 */
+static void c_cone(vec3 origin, vec3 ray, float *b, float *e, vec3 axis, float slope, int z_variant) {
+    float z0, ray_par_len, a, hb, c;
+    if (z_variant) {
+        z0 = origin.z;
+        ray_par_len = ray.z;
+        vec2 rel_perp = {origin.x, origin.y}, ray_perp = {ray.x, ray.y};
+        float ray_perp_len2 = dot2(ray_perp, ray_perp);
+        float rel_perp_len2 = dot2(rel_perp, rel_perp);
+        a = ray_perp_len2 - ray_par_len * ray_par_len;
+        hb = dot2(rel_perp, ray_perp) - ray_par_len * z0;
+        c = rel_perp_len2 - z0 * z0;
+        FL(6);
+    } else {
+        const float s2 = slope * slope;
+        z0 = dot3(origin, axis);
+        ray_par_len = dot3(ray, axis);
+        vec3 rel_par = lscale3(z0, axis);
+        vec3 rel_perp = sub3(origin, rel_par);
+        vec3 ray_par = lscale3(ray_par_len, axis);
+        vec3 ray_perp = sub3(ray, ray_par);
+        float ray_perp_len2 = dot3(ray_perp, ray_perp);
+        float rel_perp_len2 = dot3(rel_perp, rel_perp);
+        a = ray_perp_len2 - s2 * ray_par_len * ray_par_len;
+        hb = dot3(rel_perp, ray_perp) - s2 * ray_par_len * z0;
+        c = rel_perp_len2 - s2 * z0 * z0;
+        FL(10);
+    }
+    float discr = hb * hb - a * c;
+    FL(4);
+    if (discr < 0) { *b = 1; *e = 0; return; }
+    float sq = sqrtf(discr);
+    float dist1, dist2, dist = (-hb - sq) / a;
+    FL(12);
+    if (a >= 0) { dist1 = dist; dist2 = dist + 2 * sq / a; }
+    else { dist2 = dist; dist1 = dist + 2 * sq / a; }
+    float z1 = z0 + ray_par_len * dist1;
+    float z2 = z0 + ray_par_len * dist2;
+    if (z1 < 0 && z2 < 0) { *b = 1; *e = 0; }
+    else {
+        if (z1 < 0) *b = dist2;
+        else if (z2 < 0) *e = dist1;
+        else { *b = dist1; *e = dist2; }
+    }
+}
+
+/* objects/ConvexIntersection.cl:3-47 */
+static void convex_tracer(const orc_scene *sc, const orc_object *o, vec3 origin, vec3 ray,
+                          float old_isec_dist, float *p_new, uint *p_subobject, int inside,
+                          int origin_self) {
+    float ibegin = 0.0f, iend = old_isec_dist;
+    uint subobj = 0, last_subobject = *p_subobject;
+    int offset = 0;
+    for (int i = 0; i < o->comp_count; ++i) {
+        const orc_component *c = &sc->components[o->comp_first + i];
+        uint cur_subobj = 0;
+        float cur_b = ibegin, cur_e = iend;
+        if (origin_self && last_subobject > (uint)offset) cur_subobj = last_subobject - offset;
+        vec3 rel = sub3(origin, v3p(c->pos));
+        vec3 v = v3p(c->v);
+        switch (c->kind) {
+        case ORC_C_SPHERE: c_sphere(rel, ray, &cur_b, &cur_e, c->s); break;
+        case ORC_C_HALFSPACE: c_halfspace(rel, ray, &cur_b, &cur_e, &cur_subobj, v, c->s); break;
+        case ORC_C_LAYER: c_layer(rel, ray, &cur_b, &cur_e, &cur_subobj, inside, v, c->s, 0); break;
+        case ORC_C_ZLAYER: c_layer(rel, ray, &cur_b, &cur_e, &cur_subobj, inside, v, c->s, 1); break;
+        case ORC_C_CYLINDER: c_cylinder(rel, ray, &cur_b, &cur_e, v, c->s, 0); break;
+        case ORC_C_ZCYLINDER: c_cylinder(rel, ray, &cur_b, &cur_e, v, c->s, 1); break;
+        case ORC_C_CONE: c_cone(rel, ray, &cur_b, &cur_e, v, c->s, 0); break;
+        case ORC_C_ZCONE: c_cone(rel, ray, &cur_b, &cur_e, v, c->s, 1); break;
+        }
+        FL(4);
+        if (cur_b > ibegin) { ibegin = cur_b; if (!inside) subobj = cur_subobj + offset; }
+        if (cur_e < iend) { iend = cur_e; if (inside) subobj = cur_subobj + offset; }
+        if (ibegin > iend || ibegin > old_isec_dist) return;
+        offset += c->n_subobjects;
+    }
+    if (inside) *p_new = iend;
+    else *p_new = ibegin;
+    *p_subobject = subobj;
+}
+
+/* objects/ConvexIntersection.cl:49-70 and the component normal functions */
+static vec3 convex_normal(const orc_scene *sc, const orc_object *o, vec3 pos, uint subobject) {
+    int offset = 0;
+    for (int i = 0; i < o->comp_count; ++i) {
+        const orc_component *c = &sc->components[o->comp_first + i];
+        if (subobject >= (uint)offset && subobject < (uint)(offset + c->n_subobjects)) {
+            vec3 p = sub3(pos, v3p(c->pos));
+            vec3 v = v3p(c->v);
+            uint sub = subobject - offset;
+            switch (c->kind) {
+            case ORC_C_SPHERE: return div3(p, c->s);
+            case ORC_C_HALFSPACE: return v;
+            case ORC_C_LAYER: return sub == 1 ? v : neg3(v);
+            case ORC_C_ZLAYER: return sub == 1 ? v3(0.0f, 0.0f, 1.0f) : v3(0.0f, 0.0f, -1.0f);
+            case ORC_C_CYLINDER: return div3(sub3(p, lscale3(dot3(p, v), v)), c->s);
+            case ORC_C_ZCYLINDER: return v3(p.x, p.y, 0.0f);
+            case ORC_C_CONE: {
+                float z0 = dot3(p, v);
+                vec3 rel_perp = sub3(p, lscale3(z0, v));
+                FL(1);
+                return normalize3(sub3(div3(rel_perp, c->s * z0), scale3(v, c->s)));
+            }
+            case ORC_C_ZCONE: { vec3 nn = div3(p, p.z); nn.z = -1.0f; return nn; }
+            }
+        }
+        offset += c->n_subobjects;
+    }
+    return v3(0.0f, 0.0f, 0.0f);
+}
+
+/* ---- triangle meshes ------------------------------------------------------------------ */
+
+/* objects/TriangleMesh.cl:7-57: one Moeller-Trumbore test; updates *isec_dist / *subobject */
+static inline void triangle_test(const float *vd, const int *idata, int face_index, vec3 origin,
+                                 vec3 ray, float *isec_dist, uint *subobject) {
+    const int v1i = idata[3 * face_index], v2i = idata[3 * face_index + 1], v3i = idata[3 * face_index + 2];
+    const vec3 v1 = v3p(vd + 4 * v1i), v2 = v3p(vd + 4 * v2i), vv3 = v3p(vd + 4 * v3i);
+    const vec3 e1 = sub3(v2, v1), e2 = sub3(vv3, v1);
+    const vec3 P = cross3(ray, e2);
+    const float det = dot3(e1, P);
+    const float inv_det = 1.f / det;
+    const vec3 T = sub3(origin, v1);
+    const float u = dot3(T, P) * inv_det;
+    FL(4);
+    if (u < 0.f || u > 1.f) return;
+    const vec3 Q = cross3(T, e1);
+    const float v = dot3(ray, Q) * inv_det;
+    FL(4);
+    if (v < 0.f || u + v > 1.f) return;
+    const float t = dot3(e2, Q) * inv_det;
+    FL(3);
+    if (t > 0.0f && t < *isec_dist) { *isec_dist = t; *subobject = face_index; }
+}
+
+/* objects/TriangleMesh.cl:59-75 */
+static void trimesh_tracer(const orc_scene *sc, const orc_object *o, vec3 origin, vec3 ray,
+                           float old_isec_dist, float *p_new, uint *p_subobject, int origin_self) {
+    const float *vd = sc->vector_data + 4 * o->vec_offset;
+    const int *idata = sc->integer_data + o->int_offset;
+    uint old_subobject = *p_subobject, subobject = 0;
+    float isec_dist = old_isec_dist;
+    for (int j = 0; j < o->ip[1]; ++j) {
+        if (old_subobject == (uint)j && origin_self) continue;
+        triangle_test(vd, idata, j, origin, ray, &isec_dist, &subobject);
+    }
+    if (isec_dist < old_isec_dist) { *p_new = isec_dist; *p_subobject = subobject; }
+}
+
+/* objects/TriangleMesh.cl:77-114 */
+static vec3 trimesh_normal(const orc_scene *sc, const orc_object *o, vec3 pos, uint subobject) {
+    const float *vd = sc->vector_data + 4 * o->vec_offset;
+    const int *idata = sc->integer_data + o->int_offset;
+    const int v1i = idata[3 * subobject], v2i = idata[3 * subobject + 1], v3i = idata[3 * subobject + 2];
+    const vec3 v1 = v3p(vd + 4 * v1i), v2 = v3p(vd + 4 * v2i), vv3 = v3p(vd + 4 * v3i);
+    const vec3 e1 = sub3(v2, v1), e2 = sub3(vv3, v1);
+    vec3 normal = cross3(e1, e2);
+    if (o->ip[7]) {  /* smooth shading: barycentric blend of the vertex normals */
+        const float *nd = vd + 4 * o->ip[0];
+        const vec3 f1 = sub3(v1, pos), f2 = sub3(v2, pos);
+        const float normal_length = length3(normal);
+        const vec3 tri_normal = div3(normal, length3(normal));
+        const float a3 = dot3(tri_normal, cross3(e1, f1)) / normal_length;
+        const float a2 = dot3(tri_normal, cross3(f1, e2)) / normal_length;
+        const float a1 = dot3(tri_normal, cross3(sub3(vv3, v2), f2)) / normal_length;
+        FL(3);
+        const vec3 n1 = v3p(nd + 4 * v1i), n2 = v3p(nd + 4 * v2i), n3 = v3p(nd + 4 * v3i);
+        normal = add3(add3(scale3(n1, a1), scale3(n2, a2)), scale3(n3, a3));
+    }
+    return normalize3(normal);
+}
+
+/* objects/Octree.cl:32-164 */
+#define ORC_MAX_OCTREE_DEPTH 8
+#define ORC_MAX_TOTAL_ITR 300
+static void octree_tracer(const orc_scene *sc, const orc_object *o, vec3 origin, vec3 ray,
+                          float old_isec_dist, float *p_new, uint *p_subobject, int origin_self) {
+    const float *vd = sc->vector_data + 4 * o->vec_offset;
+    const int *idata = sc->integer_data + o->int_offset;
+    const int root_data_offset = o->ip[2], face_data_length = o->ip[3];
+    const vec3 root_origin = v3p(o->fp);
+    const float root_size = o->fp[3];
+
+    const vec3 slopes = v3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
+    const int w1x = slopes.x < 0.0f, w1y = slopes.y < 0.0f, w1z = slopes.z < 0.0f;
+    const int w2x = 1 - w1x, w2y = 1 - w1y, w2z = 1 - w1z;
+    const int sgx = 1 - 2 * w1x, sgy = 1 - 2 * w1y, sgz = 1 - 2 * w1z;
+    FL(6);
+
+    const vec3 rel = sub3(root_origin, origin);
+    vec3 isec1 = mul3(slopes, add3(rel, scale3(v3((float)w1x, (float)w1y, (float)w1z), root_size)));
+    vec3 isec2 = mul3(slopes, add3(rel, scale3(v3((float)w2x, (float)w2y, (float)w2z), root_size)));
+    float isec_begin = fmaxf(fmaxf(isec1.x, isec1.y), isec1.z);
+    float isec_end = fminf(fminf(isec2.x, isec2.y), isec2.z);
+    FL(7);
+    if (isec_begin > isec_end || isec_end < 0.0f || isec_begin > old_isec_dist) return;
+
+    const int *octree_data = idata + face_data_length;
+    int ocx = 0, ocy = 0, ocz = 0;          /* integer coordinates of the current node */
+    int lcx = 0, lcy = 0, lcz = 0;          /* last bit of each */
+    int path[ORC_MAX_OCTREE_DEPTH];
+    path[0] = root_data_offset;
+    uint depth = 0;
+    uint old_subobject = *p_subobject, subobject = 0;
+    float node_size = root_size;
+
+    for (int itr = 0; itr < ORC_MAX_TOTAL_ITR; itr++) {
+        vec3 ray_pos = add3(origin, lscale3(isec_begin, ray)), node_origin = v3(0, 0, 0);
+        int child_mask = 0, data_ptr = 0, child_idx;
+
+        while (depth < ORC_MAX_OCTREE_DEPTH - 1) {       /* descend to the leaf holding ray_pos */
+            child_mask = octree_data[path[depth]];
+            data_ptr = octree_data[path[depth] + 1];
+            node_origin = add3(root_origin, scale3(v3((float)ocx, (float)ocy, (float)ocz), node_size));
+            if (child_mask == 0 || child_mask == 0x100) break;
+            const vec3 rel_coords = sub3(ray_pos, node_origin);
+            const float half = 0.5f * node_size;
+            FL(4);
+            lcx = 1 - (rel_coords.x < half);
+            lcy = 1 - (rel_coords.y < half);
+            lcz = 1 - (rel_coords.z < half);
+            child_idx = 0;
+            if (lcx > 0) child_idx += 4;
+            if (lcy > 0) child_idx += 2;
+            if (lcz > 0) child_idx += 1;
+            path[depth + 1] = data_ptr + child_idx * 2;
+            ocx = (ocx << 1) | lcx; ocy = (ocy << 1) | lcy; ocz = (ocz << 1) | lcz;
+            node_size *= 0.5f;
+            FL(1);
+            depth++;
+        }
+
+        isec2 = mul3(slopes, add3(sub3(node_origin, origin), scale3(v3((float)w2x, (float)w2y, (float)w2z), node_size)));
+        isec_end = fminf(fminf(isec2.x, isec2.y), isec2.z);
+        FL(2);
+
+        if (child_mask != 0x100) {
+            int n_triangles = octree_data[data_ptr];
+            if (n_triangles > 0) {
+                float isec_dist = isec_end;
+                for (int j = 0; j < n_triangles; ++j) {
+                    const int face_index = octree_data[data_ptr + 1 + j];
+                    if (old_subobject == (uint)face_index && origin_self) continue;
+                    triangle_test(vd, idata, face_index, origin, ray, &isec_dist, &subobject);
+                }
+                FL(1);
+                if (isec_dist < isec_end) { *p_new = isec_dist; *p_subobject = subobject; return; }
+            }
+        }
+
+        int hx = 0, hy = 0, hz = 0;                       /* step to the neighbour cell */
+        FL(3);
+        if (isec_end == isec2.x) hx = sgx;
+        else if (isec_end == isec2.y) hy = sgy;
+        else if (isec_end == isec2.z) hz = sgz;
+
+        while (depth > 0) {                               /* climb until the step stays inside */
+            lcx += hx; lcy += hy; lcz += hz;
+            if (lcx >= 0 && lcx <= 1 && lcy >= 0 && lcy <= 1 && lcz >= 0 && lcz <= 1) break;
+            depth--;
+            ocx >>= 1; ocy >>= 1; ocz >>= 1;
+            lcx = ocx & 1; lcy = ocy & 1; lcz = ocz & 1;
+            node_size *= 2.0f;
+            FL(1);
+        }
+        if (depth == 0) return;
+
+        ocx = (ocx & ~1) | lcx; ocy = (ocy & ~1) | lcy; ocz = (ocz & ~1) | lcz;
+        child_idx = 0;
+        if (lcx > 0) child_idx += 4;
+        if (lcy > 0) child_idx += 2;
+        if (lcz > 0) child_idx += 1;
+        data_ptr = octree_data[path[depth - 1] + 1];
+        path[depth] = data_ptr + child_idx * 2;
+
+        isec_begin = isec_end;
+        FL(1);
+        if (isec_begin > old_isec_dist) return;
+    }
+}
+
+/* ---- quaternion Julia set, distance estimator: objects/QuaternionJuliaSet2.cl:6-123 ---- */
+static inline vec4 quat_mult(vec4 q1, vec4 q2) {      /* static.cl:87-93 */
+    vec3 a = v3(q1.y, q1.z, q1.w), b = v3(q2.y, q2.z, q2.w);
+    vec3 im = add3(add3(lscale3(q1.x, b), lscale3(q2.x, a)), cross3(a, b));
+    vec4 r = {q1.x * q2.x - dot3(a, b), im.x, im.y, im.z};
+    FL(2);
+    return r;
+}
+static inline vec4 quat_square(vec4 q) {              /* static.cl:95-101 */
+    vec3 a = v3(q.y, q.z, q.w);
+    float two_r = 2 * q.x;
+    vec4 r = {q.x * q.x - dot3(a, a), two_r * q.y, two_r * q.z, two_r * q.w};
+    FL(6);
+    return r;
+}
+
+/* objects/bounding_volumes.cl:3-27; returns 0 when the ray misses the bounding sphere */
+static int bounding_sphere(vec3 origin, vec3 ray, float R2, float old_isec_dist, float *tmin, float *tmax) {
+    float dotp = -dot3(ray, origin);
+    float psq = dot3(origin, origin);
+    int inside_bnd = psq < R2;
+    FL(3);
+    if (dotp <= 0 && !inside_bnd) return 0;
+    const float discr = dotp * dotp - psq + R2;
+    FL(4);
+    if (discr < 0) return 0;
+    const float sq = sqrtf(discr);
+    FL(6);
+    *tmin = fmaxf(dotp - sq, 0.0f);
+    *tmax = fminf(dotp + sq, old_isec_dist);
+    if (*tmax <= *tmin) return 0;
+    return 1;
+}
+
+static void qjs2_tracer(const orc_object *o, vec3 origin, vec3 ray, float old_isec_dist,
+                        float *p_new, int origin_self) {
+    if (origin_self) return;
+    float trace_begin, trace_end;
+    const float bndR = o->fp[4];
+    FL(1);
+    if (!bounding_sphere(origin, ray, bndR * bndR, old_isec_dist, &trace_begin, &trace_end)) return;
+    const int MAX_ITER = o->ip[1], julia_itr = o->ip[0];
+    const float TARGET_EPS = o->fp[5], MAX_STEP = o->fp[6];
+    const vec4 c = {o->fp[0], o->fp[1], o->fp[2], o->fp[3]};
+    float step, dist = trace_begin;
+    vec3 pos = add3(lscale3(trace_begin, ray), origin);
+    for (int i = 0; i < MAX_ITER; i++) {
+        vec4 q = {pos.x, pos.y, pos.z, 0}, qd = {1, 0, 0, 0};
+        float gr = ray.x, gi = ray.y, gj = ray.z, gk = 0;
+        for (int iii = 0; iii < julia_itr; ++iii) {
+            /* the derivative-chain branch of the reference is dead code here: origin_self is false */
+            vec4 m = quat_mult(q, qd);
+            qd.x = 2 * m.x; qd.y = 2 * m.y; qd.z = 2 * m.z; qd.w = 2 * m.w;
+            vec4 sq = quat_square(q);
+            q.x = sq.x + c.x; q.y = sq.y + c.y; q.z = sq.z + c.z; q.w = sq.w + c.w;
+            FL(8);
+        }
+        float l = sqrtf(dot4(q, q));
+        step = 0.5f * l * logf(l) / sqrtf(dot4(qd, qd));
+        step = fminf(step, MAX_STEP);
+        FL(8);
+        (void)gr; (void)gi; (void)gj; (void)gk;
+        if (step < TARGET_EPS) { *p_new = dist + step; return; }
+        dist += step;
+        if (dist > trace_end) return;
+        pos = add3(pos, lscale3(step, ray));
+    }
+}
+
+static vec3 qjs2_normal(const orc_object *o, vec3 pos) {
+    vec4 q = {pos.x, pos.y, pos.z, 0};
+    const vec4 c = {o->fp[0], o->fp[1], o->fp[2], o->fp[3]};
+    vec3 gr = v3(1, 0, 0), gi = v3(0, 1, 0), gj = v3(0, 0, 1), gk = v3(0, 0, 0);
+    for (int iii = 0; iii < o->ip[0]; ++iii) {
+        vec3 gr1 = lscale3(2, sub3(sub3(sub3(lscale3(q.x, gr), lscale3(q.y, gi)), lscale3(q.z, gj)), lscale3(q.w, gk)));
+        vec3 gi1 = lscale3(2, add3(scale3(gr, q.y), lscale3(q.x, gi)));
+        vec3 gj1 = lscale3(2, add3(scale3(gr, q.z), lscale3(q.x, gj)));
+        vec3 gk1 = lscale3(2, add3(scale3(gr, q.w), lscale3(q.x, gk)));
+        gr = gr1; gi = gi1; gj = gj1; gk = gk1;
+        vec4 sq = quat_square(q);
+        q.x = sq.x + c.x; q.y = sq.y + c.y; q.z = sq.z + c.z; q.w = sq.w + c.w;
+        FL(4);
+    }
+    vec3 grad = normalize3(lscale3(2, add3(add3(add3(lscale3(q.x, gr), lscale3(q.y, gi)), lscale3(q.z, gj)), lscale3(q.w, gk))));
+    if (isfinite(grad.x) && isfinite(grad.y) && isfinite(grad.z)) return grad;
+    return v3(1, 0, 0);
+}
+
+/* ---- quaternion Julia set, interval arithmetic: objects/QuaternionJuliaSet.cl:2-33 plugged
+ *      into the implicit-surface loop (fp[0..3] = c, ip[0] = julia_itr) ---- */
+static ia_type qjs_ia_f(ia_type x, ia_type y, ia_type z, const void *ctx) {
+    const orc_object *o = (const orc_object *)ctx;
+    ia_type qr = x, qi = y, qj = z, qk = ia_new(0.0f, 0.0f);
+    const float cr = o->fp[0], ci = o->fp[1], cj = o->fp[2], ck = o->fp[3];
+    for (int iii = 0; iii < o->ip[0]; ++iii) {
+        const ia_type qr1 = ia_sub(ia_pow2(qr), ia_pow2(qi) + ia_pow2(qj) + ia_pow2(qk)) + cr;
+        qi = 2 * ia_mul(qr, qi) + ci;
+        qj = 2 * ia_mul(qr, qj) + cj;
+        qk = 2 * ia_mul(qr, qk) + ck;
+        qr = qr1;
+        FL(40);
+    }
+    FL(16);
+    return ia_pow2(qr) + ia_pow2(qi) + ia_pow2(qj) + ia_pow2(qk) - 4.0f;
+}
+static ia_type qjs_ia_df(const ia_type ray[3], const ia_type origin[3], ia_type t, const void *ctx) {
+    (void)ray; (void)origin; (void)t; (void)ctx;
+    return ia_new_exact(1.0f);
+}
+static void qjs_ia_tracer(const orc_object *o, vec3 origin, vec3 ray, float old_isec_dist, float *p_new,
+                          int inside, int origin_self) {
+    const float og[3] = {origin.x, origin.y, origin.z}, rg[3] = {ray.x, ray.y, ray.z};
+    const orc_ia_rayfn fn = {qjs_ia_f, qjs_ia_df, o};
+    /* implicit_surface.py:11-22 via julia_sets.py:9-14: bndR = 1.5, no self intersection */
+    orc_implicit_tracer(&fn, og, rg, old_isec_dist, p_new, inside, origin_self, 1, 1,
+                        o->fp[4] * o->fp[4], o->ip[1], o->fp[5]);
+}
+
+/* ---- dispatch --------------------------------------------------------------------------- */
+
+static void shape_tracer(const orc_scene *sc, const orc_object *o, vec3 origin, vec3 ray,
+                         float old_isec_dist, float *p_new, uint *p_subobject, int inside,
+                         int origin_self) {
+    switch (o->kind) {
+    case ORC_SPHERE: sphere_tracer(origin, ray, p_new, inside); break;
+    case ORC_HALFSPACE: halfspace_tracer(origin, ray, p_new); break;
+    case ORC_CONVEX: convex_tracer(sc, o, origin, ray, old_isec_dist, p_new, p_subobject, inside, origin_self); break;
+    case ORC_TRIMESH: trimesh_tracer(sc, o, origin, ray, old_isec_dist, p_new, p_subobject, origin_self); break;
+    case ORC_OCTREE: octree_tracer(sc, o, origin, ray, old_isec_dist, p_new, p_subobject, origin_self); break;
+    case ORC_QJS2: qjs2_tracer(o, origin, ray, old_isec_dist, p_new, origin_self); break;
+    case ORC_QJS_IA: qjs_ia_tracer(o, origin, ray, old_isec_dist, p_new, inside, origin_self); break;
+    default: {
+        float og[3] = {origin.x, origin.y, origin.z}, rg[3] = {ray.x, ray.y, ray.z};
+        o->tracer(og, rg, old_isec_dist, p_new, p_subobject, inside, origin_self);
+    }
+    }
+}
+
+static vec3 shape_normal(const orc_scene *sc, const orc_object *o, vec3 pos, uint subobject) {
+    switch (o->kind) {
+    case ORC_SPHERE: return pos;
+    case ORC_HALFSPACE: return v3(1.0f, 0.0f, 0.0f);
+    case ORC_CONVEX: return convex_normal(sc, o, pos, subobject);
+    case ORC_TRIMESH: case ORC_OCTREE: return trimesh_normal(sc, o, pos, subobject);
+    case ORC_QJS2: return qjs2_normal(o, pos);
+    case ORC_QJS_IA: FL(3); return normalize3(v3(2 * pos.x, 2 * pos.y, 2 * pos.z));   /* gradient of x^2+y^2+z^2-1 */
+    default: {
+        float pg[3] = {pos.x, pos.y, pos.z}, ng[3] = {0, 0, 0};
+        o->normal(pg, subobject, ng);
+        return v3p(ng);
+    }
+    }
+}
+
+/* tracer.cl:72-141: closest-hit step for one object */
+static void trace_object(const orc_scene *sc, int object_id, vec3 pos, vec3 ray, float *isec_dist,
+                         uint *whichobject, uint *which_subobject, uint last_whichobject,
+                         uint last_which_subobject, uint inside) {
+    const orc_object *o = &sc->objects[object_id - 1];
+    const int inside_current = inside == (uint)object_id, origin_self = last_whichobject == (uint)object_id;
+    if (o->convex && !(!origin_self || inside_current)) return;
+    float new_isec_dist = 0;
+    uint cur_subobject = last_which_subobject;
+    const vec3 local_pos = affine_tf(o->inv, pos);
+    const vec3 local_ray = linear_tf(o->inv, ray);
+    const float stretch = length3(local_ray);
+    FL(1);
+    shape_tracer(sc, o, local_pos, div3(local_ray, stretch), *isec_dist * stretch, &new_isec_dist,
+                 &cur_subobject, inside_current, origin_self);
+    FL(1);
+    if (new_isec_dist > 0) {
+        new_isec_dist /= stretch;
+        FL(2);
+        if (new_isec_dist < *isec_dist) {
+            *isec_dist = new_isec_dist;
+            *which_subobject = cur_subobject;
+            *whichobject = object_id;
+        }
+    }
+}
+
+/* tracer.cl:223-284 (pos is already advanced to the hit point) */
+static vec3 surface_normal(const orc_scene *sc, int object_id, vec3 pos, vec3 ray, uint subobject, uint inside) {
+    const orc_object *o = &sc->objects[object_id - 1];
+    const vec3 local_pos = affine_tf(o->inv, pos);
+    vec3 normal = shape_normal(sc, o, local_pos, subobject);
+    normal = normalize3(transposed_linear_tf(o->inv, normal));
+    if (o->auto_flip_normal) { FL(1); if (dot3(normal, ray) > 0) normal = neg3(normal); }
+    else if (inside == (uint)object_id) normal = neg3(normal);
+    return normal;
+}
+
+/* shader.cl:355-369 + tracer.cl:143-221 over all objects */
+static float light_visibility(const orc_scene *sc, vec3 pos, vec3 normal, uint whichobject,
+                              uint which_subobject, uint inside, int diffusions_left, vec3 dest, int light_id) {
+    if (diffusions_left < 1) return 0.0f;
+    vec3 ray = sub3(dest, pos);
+    FL(1);
+    if (dot3(normal, ray) < 0.0f) return 0.0f;
+    const float isec_dist = length3(ray);
+    ray = div3(ray, isec_dist);
+    float shadow_mask = 1.0f;
+    for (int object_id = 1; object_id <= sc->n_objects; ++object_id) {
+        if (object_id == light_id) continue;
+        const orc_object *o = &sc->objects[object_id - 1];
+        uint subobject = which_subobject;
+        const int inside_current = inside == (uint)object_id, origin_self = whichobject == (uint)object_id;
+        float new_isec_dist = 0;
+        if (o->convex && !(!origin_self || inside_current)) continue;
+        const vec3 local_pos = affine_tf(o->inv, pos);
+        const vec3 local_ray = linear_tf(o->inv, ray);
+        const float stretch = length3(local_ray);
+        FL(1);
+        shape_tracer(sc, o, local_pos, div3(local_ray, stretch), isec_dist * stretch, &new_isec_dist,
+                     &subobject, inside_current, origin_self);
+        FL(1);
+        if (new_isec_dist > 0) {
+            new_isec_dist /= stretch;
+            FL(2);
+            if (new_isec_dist < isec_dist) shadow_mask = 0.0f;
+        }
+    }
+    return shadow_mask;
+}
+
+/* ====================================================================================
+ * shading (shader.cl:18-353) and Russian roulette (shader.cl:371-434, group of one ray)
+ * ==================================================================================== */
+
+typedef struct {
+    vec3 pos, ray;
+    vec3 ray_color;        /* spectral mode uses .x only */
+    uint whichobject, which_subobject, inside;
+    int diffusions_left, suppress_emission;
+} path_state;
+
+typedef struct {
+    vec3 rvec; float p;
+    vec3 gauss; float russian;
+    vec3 light_point; float light_area;
+    vec3 light_normal; float min_light_sampling_distance;
+    vec3 light_center; int light_id;
+} bounce_sample;
+
+typedef struct { const orc_scene *sc; const float *row; int stride; } material_view;
+
+enum { M_DIFFUSE, M_EMISSION, M_REFLECTION, M_TRANSPARENCY, M_VOLUME_ABSORPTION,      /* rgb colours */
+       S_IOR = 0, S_VOLUME_SCATTERING, S_VOLUME_SCATTERING_BLUR, S_REFLECTION_BLUR, S_TRANSPARENCY_BLUR };
+/* spectral property order (shader.py:129-142) */
+enum { P_DIFFUSE, P_EMISSION, P_REFLECTION, P_TRANSPARENCY, P_VOLUME_SCATTERING, P_VOLUME_ABSORPTION,
+       P_REFLECTION_BLUR, P_TRANSPARENCY_BLUR, P_VOLUME_SCATTERING_BLUR, P_IOR };
+
+static const int rgb_color_to_spectral[5] = {P_DIFFUSE, P_EMISSION, P_REFLECTION, P_TRANSPARENCY, P_VOLUME_ABSORPTION};
+static const int rgb_scalar_to_spectral[5] = {P_IOR, P_VOLUME_SCATTERING, P_VOLUME_SCATTERING_BLUR, P_REFLECTION_BLUR, P_TRANSPARENCY_BLUR};
+
+static inline vec3 mat_color(const material_view *m, int prop, uint id) {
+    if (m->sc->rgb) return v3p(m->sc->material_colors + 4 * (prop * m->stride + id));
+    float s = m->row[rgb_color_to_spectral[prop] * m->stride + id];
+    return v3(s, s, s);
+}
+static inline float mat_scalar(const material_view *m, int prop, uint id) {
+    if (m->sc->rgb) return m->sc->material_scalars[prop * m->stride + id];
+    return m->row[rgb_scalar_to_spectral[prop] * m->stride + id];
+}
+static inline float color2prob(const orc_scene *sc, vec3 c) {
+    if (sc->rgb) { FL(1); return dot3(c, v3(1.0f, 1.0f, 1.0f)) / 3.0f; }
+    return c.x;
+}
+/* colour (rgb triple, or a scalar replicated in xyz) -> contribution to the rgb image */
+static inline vec3 to_rgb(const orc_scene *sc, vec3 c, vec3 cmask) {
+    if (sc->rgb) return c;
+    return lscale3(c.x, cmask);
+}
+
+static int shade(const orc_scene *sc, const material_view *m, path_state *s, vec3 n, float last_distance,
+                 float shadow_mask, const bounce_sample *B, int is_last, vec3 cmask, vec3 *img) {
+    const int rgb = sc->rgb;
+    float p = B->p;
+    vec3 r = s->ray;
+    vec3 gauss_rvec = B->gauss;
+    float cur_prob = 0.0f;
+    vec3 cur_col, pipeline_color;
+
+    /* volumetric: shader.cl:124-170 */
+    {
+        float last_dist = last_distance;
+        const float alpha = mat_scalar(m, S_VOLUME_SCATTERING, s->inside);
+        FL(1);
+        if (alpha > 0) { cur_prob = 1.0f - expf(-alpha * last_dist); FL(3); }
+        FL(1);
+        if (p < cur_prob) {
+            float d = -logf(1.0f - p) / alpha;
+            FL(4);
+            s->pos = sub3(s->pos, lscale3(last_dist - d, r));
+            last_dist = d;
+            s->whichobject = 0;
+            const float blur = mat_scalar(m, S_VOLUME_SCATTERING_BLUR, s->inside);
+            if (blur < 1.0f) { FL(4); r = normalize3(add3(gauss_rvec, scale3(r, tanf(PI_F * 0.5f * (1.0f - blur))))); }
+            else r = B->rvec;
+            if (sc->bidirectional) s->suppress_emission = 0;
+            p = -1.0f;
+        }
+        else { p -= cur_prob; FL(1); }
+
+        cur_col = mat_color(m, M_VOLUME_ABSORPTION, s->inside);
+        if (rgb) { FL(6); pipeline_color = v3(expf(-cur_col.x * last_dist), expf(-cur_col.y * last_dist), expf(-cur_col.z * last_dist)); }
+        else { FL(2); float e = expf(-cur_col.x * last_dist); pipeline_color = v3(e, e, e); }
+        if (p < 0.0f) { s->ray = r; s->ray_color = mul3(s->ray_color, pipeline_color); }
+    }
+
+    /* emission: shader.cl:172-188 */
+    if (p >= 0.0f) {
+        int emit = 1;
+        if (sc->bidirectional) {
+            const int suppressed = s->suppress_emission;
+            emit = (suppressed >= 0 && s->whichobject != (uint)suppressed) || s->whichobject == (uint)(-suppressed);
+        }
+        if (emit)
+            *img = add3(*img, to_rgb(sc, mul3(mul3(mat_color(m, M_EMISSION, s->whichobject), s->ray_color), pipeline_color), cmask));
+    }
+    if (is_last) return 0;
+
+    /* specular reflection: shader.cl:190-217 */
+    if (p >= 0.0f) {
+        cur_col = mat_color(m, M_REFLECTION, s->whichobject);
+        cur_prob = color2prob(sc, cur_col);
+        FL(1);
+        if (p < cur_prob) {
+            if (rgb) pipeline_color = mul3(pipeline_color, div3(cur_col, cur_prob));
+            FL(1);
+            r = sub3(r, lscale3(2 * dot3(r, n), n));
+            const float blur = mat_scalar(m, S_REFLECTION_BLUR, s->whichobject);
+            if (blur > 0) {
+                FL(2);
+                if (dot3(n, gauss_rvec) < 0) gauss_rvec = neg3(gauss_rvec);
+                r = normalize3(add3(scale3(gauss_rvec, blur), scale3(r, 1.0f - blur)));
+            }
+            if (sc->bidirectional) s->suppress_emission = 0;
+            p = -1.0f;
+            s->ray = r; s->ray_color = mul3(s->ray_color, pipeline_color);
+        }
+        else { p -= cur_prob; FL(1); }
+    }
+
+    /* refraction: shader.cl:219-288 */
+    if (p >= 0.0f) {
+        cur_col = mat_color(m, M_TRANSPARENCY, s->whichobject);
+        cur_prob = color2prob(sc, cur_col);
+        FL(1);
+        if (p < cur_prob) {
+            if (rgb) pipeline_color = mul3(pipeline_color, div3(cur_col, cur_prob));
+            float dotp = dot3(r, n);
+            FL(1);
+            if (dotp > 0) { n = neg3(n); dotp = -dotp; }
+            float nfrac = 0;
+            const float ior1 = mat_scalar(m, S_IOR, s->whichobject);
+            const float ior0 = mat_scalar(m, S_IOR, 0);
+            FL(1);
+            if (s->inside == s->whichobject) { nfrac = ior1 / ior0; s->inside = 0; }
+            else { nfrac = ior0 / ior1; s->inside = s->whichobject; }
+            if (nfrac != 1) {
+                const float cos2t = 1 - nfrac * nfrac * (1 - dotp * dotp);
+                FL(6);
+                if (cos2t < 0) {
+                    FL(1);
+                    r = sub3(r, lscale3(2 * dotp, n));
+                    if (s->inside == s->whichobject) s->inside = 0;
+                    else s->inside = s->whichobject;
+                }
+                else { FL(3); r = normalize3(add3(scale3(r, nfrac), scale3(n, -dotp * nfrac - sqrtf(cos2t)))); }
+            }
+            FL(1);
+            if (dot3(n, r) < 0) n = neg3(n);
+            const float blur = mat_scalar(m, S_TRANSPARENCY_BLUR, s->whichobject);
+            if (blur > 0) {
+                FL(2);
+                if (dot3(n, gauss_rvec) < 0) gauss_rvec = neg3(gauss_rvec);
+                r = normalize3(add3(scale3(gauss_rvec, blur), scale3(r, 1.0f - blur)));
+            }
+            if (sc->bidirectional) s->suppress_emission = 0;
+            p = -1.0f;
+            s->ray = r; s->ray_color = mul3(s->ray_color, pipeline_color);
+        }
+        else { p -= cur_prob; FL(1); }
+    }
+
+    /* diffuse: shader.cl:291-353 */
+    if (p >= 0.0f) {
+        if (sc->bidirectional) s->suppress_emission = 0;
+        cur_col = mat_color(m, M_DIFFUSE, s->whichobject);
+        cur_prob = color2prob(sc, cur_col);
+        FL(1);
+        if (cur_prob > 0.0f && s->diffusions_left > 0) {
+            pipeline_color = mul3(pipeline_color, cur_col);
+            s->diffusions_left -= 1;
+            if (sc->bidirectional && B->light_id > 0) {
+                FL(1);
+                if (length3(sub3(s->pos, B->light_center)) > B->min_light_sampling_distance) {
+                    vec3 shadow_ray = sub3(B->light_point, s->pos);
+                    s->suppress_emission = B->light_id;
+                    FL(2);
+                    if (dot3(shadow_ray, n) > 0 && dot3(shadow_ray, B->light_normal) < 0) {
+                        const float shadow_dist = length3(shadow_ray);
+                        shadow_ray = normalize3(shadow_ray);
+                        const float geom = dot3(n, shadow_ray) / PI_F
+                            * dot3(neg3(shadow_ray), B->light_normal) / (shadow_dist * shadow_dist);
+                        FL(4);
+                        vec3 c = to_rgb(sc, mul3(lscale3(geom, s->ray_color), pipeline_color), cmask);
+                        c = mul3(c, mat_color(m, M_EMISSION, B->light_id));
+                        c = scale3(c, shadow_mask);
+                        c = scale3(c, B->light_area);
+                        *img = add3(*img, c);
+                    }
+                }
+                else if (s->diffusions_left == 0) {
+                    s->diffusions_left = 1;
+                    s->suppress_emission = -B->light_id;
+                }
+            }
+            r = B->rvec;
+            FL(2);
+            if (dot3(n, r) < 0) r = neg3(r);
+            pipeline_color = scale3(pipeline_color, 2.0f * dot3(n, r));
+        }
+        else pipeline_color = scale3(pipeline_color, 0.0f);
+        p = -1.0f;
+        s->ray = r; s->ray_color = mul3(s->ray_color, pipeline_color);
+    }
+
+    /* Russian roulette on the single ray: shader.cl:371-434 with group size 1 */
+    {
+        const float cur_intensity = color2prob(sc, s->ray_color);
+        float survive = cur_intensity, russian_prob = 1.0f;
+        if (sc->min_russian_prob != 0.0f) {
+            FL(4);
+            if (cur_intensity > 0.0f) {
+                russian_prob = fminf(fmaxf(cur_intensity, sc->min_russian_prob), 1.0f);
+                if (B->russian > russian_prob) survive = 0.0f;
+            }
+        }
+        if (survive == 0.0f) return 0;
+        if (sc->min_russian_prob != 0.0f && russian_prob < 1.0f) s->ray_color = div3(s->ray_color, russian_prob);
+    }
+    return 1;
+}
+
+/* ====================================================================================
+ * per-pixel driver
+ * ==================================================================================== */
+
+static bounce_sample load_bounce(const float *rec) {
+    bounce_sample B;
+    B.rvec = v3p(rec); B.p = rec[3];
+    B.gauss = v3p(rec + 4); B.russian = rec[7];
+    B.light_point = v3p(rec + 8); B.light_area = rec[11];
+    B.light_normal = v3p(rec + 12); B.min_light_sampling_distance = rec[15];
+    B.light_center = v3p(rec + 16); memcpy(&B.light_id, rec + 19, 4);
+    return B;
+}
+
+/* static.cl:109-131 + renderer.py:305-311 */
+static void start_path(const orc_scene *sc, path_state *s, const float *rec, vec3 base_ray) {
+    const vec3 rot_ray = v3(dot3(v3p(rec), base_ray), dot3(v3p(rec + 4), base_ray), dot3(v3p(rec + 8), base_ray));
+    const float sharp_distance = rec[15];
+    FL(1);
+    if (sharp_distance > 0.0f) s->ray = normalize3(sub3(lscale3(sharp_distance, rot_ray), v3p(rec + 12)));
+    else s->ray = rot_ray;
+    s->pos = v3p(rec + 16);
+    s->ray_color = scale3(v3(1.0f, 1.0f, 1.0f), rec[19]);
+    s->whichobject = 0;
+    s->which_subobject = 0;
+    s->inside = sc->root_object_id;
+    s->diffusions_left = sc->min_bounces;
+    s->suppress_emission = 0;
+}
+
+static inline void put4(float *d, float a, float b, float c, float e) { d[0] = a; d[1] = b; d[2] = c; d[3] = e; }
+static inline float as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+
+/* renderer.py:326-433 for one ray */
+static int segment(const orc_scene *sc, const material_view *m, path_state *s, const bounce_sample *B,
+                   int is_last, vec3 cmask, vec3 *img, float *dbg) {
+    float isec_dist = sc->max_ray_length;
+    const uint last_whichobject = s->whichobject, last_which_subobject = s->which_subobject;
+    uint whichobject = 0, which_subobject = last_which_subobject;
+    for (int id = 1; id <= sc->n_objects; ++id)
+        trace_object(sc, id, s->pos, s->ray, &isec_dist, &whichobject, &which_subobject,
+                     last_whichobject, last_which_subobject, s->inside);
+    if (whichobject == 0) {
+        if (dbg) { put4(dbg, 0.0f, 0.0f, as_float((int)s->inside), as_float(s->diffusions_left));
+                   put4(dbg + 4, isec_dist, 0.0f, 0.0f, 0.0f); }
+        return 0;
+    }
+    s->whichobject = whichobject;
+    s->which_subobject = which_subobject;
+    s->pos = add3(s->pos, lscale3(isec_dist, s->ray));
+    const vec3 normal = surface_normal(sc, whichobject, s->pos, s->ray, which_subobject, s->inside);
+    float shadow_mask = 0.0f;
+    if (sc->bidirectional && !is_last)
+        shadow_mask = light_visibility(sc, s->pos, normal, whichobject, which_subobject, s->inside,
+                                       s->diffusions_left, B->light_point, B->light_id);
+    const vec3 hit_pos = s->pos;
+    const int alive = shade(sc, m, s, normal, isec_dist, shadow_mask, B, is_last, cmask, img);
+    if (dbg) {
+        put4(dbg, as_float((int)whichobject), as_float((int)which_subobject), as_float((int)s->inside), as_float(s->diffusions_left));
+        put4(dbg + 4, isec_dist, alive ? 1.0f : 0.0f, shadow_mask, as_float(s->suppress_emission));
+        put4(dbg + 8, hit_pos.x, hit_pos.y, hit_pos.z, 0.0f);
+        put4(dbg + 12, s->ray.x, s->ray.y, s->ray.z, 0.0f);
+        put4(dbg + 16, normal.x, normal.y, normal.z, 0.0f);
+        put4(dbg + 20, s->ray_color.x, s->ray_color.y, s->ray_color.z, 0.0f);
+    }
+    return alive;
+}
+
+int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, const float *bounce_tape,
+               const float *material_rows, int n_pixels, int n_passes, float *img, float *dbg,
+               int n_threads, double *flops) {
+    const int stride = sc->n_objects + 1;
+    const int row_len = 10 * stride;
+    double total_flops = 0.0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    #pragma omp parallel for schedule(dynamic, 256) reduction(+ : total_flops)
+    for (int k = 0; k < n_pixels; ++k) {
+#ifdef ORC_COUNT_FLOPS
+        orc_flops = 0.0;
+#endif
+        const vec3 base_ray = v3p(cam + 4 * k);
+        vec3 acc = v3p(img + 4 * k);
+        for (int pass = 0; pass < n_passes; ++pass) {
+            const float *prec = pass_tape + (size_t)pass * ORC_PASS_RECORD * 4;
+            path_state s;
+            start_path(sc, &s, prec, base_ray);
+            if (!sc->rgb) { s.ray_color.y = s.ray_color.x; s.ray_color.z = s.ray_color.x; }
+            const vec3 cmask = v3p(prec + 20);
+            material_view m = {sc, material_rows ? material_rows + (size_t)pass * row_len : 0, stride};
+            for (int b = 0; b < sc->max_bounces; ++b) {
+                const bounce_sample B = load_bounce(bounce_tape + ((size_t)pass * sc->max_bounces + b) * ORC_BOUNCE_RECORD * 4);
+                float *d = dbg ? dbg + ((size_t)b * n_pixels + k) * ORC_DEBUG_RECORD * 4 : 0;
+                if (!segment(sc, &m, &s, &B, b == sc->max_bounces - 1, cmask, &acc, d)) break;
+            }
+        }
+        img[4 * k] = acc.x; img[4 * k + 1] = acc.y; img[4 * k + 2] = acc.z;
+#ifdef ORC_COUNT_FLOPS
+        total_flops += orc_flops;
+#endif
+    }
+    if (flops) *flops = total_flops;
+    return 0;
+}
+
+int orc_first_hit(const orc_scene *sc, const float *cam, const float *pass_tape, int n_pixels,
+                  int *out_ids, float *out_t, float *out_normal, int n_threads) {
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    #pragma omp parallel for schedule(static)
+    for (int k = 0; k < n_pixels; ++k) {
+        path_state s;
+        start_path(sc, &s, pass_tape, v3p(cam + 4 * k));
+        float isec_dist = sc->max_ray_length;
+        uint whichobject = 0, which_subobject = 0;
+        for (int id = 1; id <= sc->n_objects; ++id)
+            trace_object(sc, id, s.pos, s.ray, &isec_dist, &whichobject, &which_subobject, 0, 0, s.inside);
+        vec3 normal = v3(0.0f, 0.0f, 0.0f);
+        if (whichobject != 0)
+            normal = surface_normal(sc, whichobject, add3(s.pos, lscale3(isec_dist, s.ray)), s.ray, which_subobject, s.inside);
+        out_ids[2 * k] = (int)whichobject;
+        out_ids[2 * k + 1] = (int)which_subobject;
+        out_t[k] = isec_dist;
+        put4(out_normal + 4 * k, normal.x, normal.y, normal.z, 0.0f);
+    }
+    return 0;
+}

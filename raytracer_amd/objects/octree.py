@@ -34,6 +34,14 @@ class Octree(Tracer):
         return self.triangle_mesh.auto_flip_normal
 
     @property
+    def shading(self):
+        # The reference's shared normal template tests `obj.shading` on the Octree itself,
+        # where the attribute does not exist; Jinja's Undefined then selects the smooth
+        # branch, which reads vertex normals past the mesh's own data.  Here the octree
+        # shades like the mesh it wraps.
+        return self.triangle_mesh.shading
+
+    @property
     def coordinates(self):
         return self.triangle_mesh.coordinates
 
