@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the hot path: sample passes of scene-dev at 1080p on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step = one launch of the fused render kernel over `--passes-per-step` sample passes of the
+whole frame (inputs - camera rays, random tape, scene tables - already resident in HBM).
+With N > 1 (launched by torch.distributed.run, one process per GPU) the passes are striped
+over the ranks (pass j belongs to rank j mod N), every rank keeps a private
+accumulator and one RCCL all-reduce at the end of the timed region sums them; per-GPU work
+is fixed, so scaling is "weak".  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import runpy
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP32_VECTOR_TFLOPS = 157.3        # packed v_pk_fma_f32 (= the dense FP32 MFMA peak)
+PEAK_FP32_SCALAR_FMA_TFLOPS = 78.6     # one v_fma_f32 per lane per issue
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--passes-per-step', type=int, default=32)
+    ap.add_argument('--scene', default='scene-dev')
+    ap.add_argument('--size', default='1920x1080')
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--regenerate', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0,
+                    help='target duration of the CPU baseline sample')
+    return ap.parse_args()
+
+
+def stripe(tape, rank, world):
+    return tuple(x[rank::world] if x is not None else None for x in tape)
+
+
+def cpu_baseline(renderer, tape, target_seconds):
+    """Time the CPU oracle ("port") on a bounded sample of the same workload and count the
+    algorithmic FP32 operations per sample with its instrumented build."""
+    from oracle import oracle
+    osc = oracle.OracleScene(renderer)
+    threads = int(os.environ.get('OMP_NUM_THREADS', 0)) or min(os.cpu_count() or 1, 16)
+    one = tuple(x[:1] if x is not None else None for x in tape)
+    _, _, flops = osc.render(one, n_threads=threads, count_flops=True)
+    flops_per_sample = flops / renderer.n_pixels
+    t0 = time.time()
+    osc.render(one, n_threads=threads)
+    t_one = time.time() - t0
+    n = int(max(1, min(tape[0].shape[0], target_seconds / max(t_one, 1e-3))))
+    sample = tuple(x[:n] if x is not None else None for x in tape)
+    t0 = time.time()
+    osc.render(sample, n_threads=threads)
+    dt = time.time() - t0
+    return {
+        'value': renderer.n_pixels * n / dt / 1e6, 'unit': 'Msamples/s', 'cores': threads,
+        'kind': 'port',
+        'sample': '%d sample passes of the same %dx%d frame, same tape (%.1f s of CPU work)'
+                  % (n, renderer.img_shape[1], renderer.img_shape[0], dt),
+    }, flops_per_sample
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the HIP back end has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from raytracer_amd.renderer import Renderer
+    width, height = (int(v) for v in args.size.lower().split('x'))
+    scene = runpy.run_path(os.path.join(ROOT, 'raytracer_amd', 'scenes', args.scene + '.py'))['scene']
+    scene.image.size = (width, height)
+    scene.samples_per_pixel = (args.steps + args.warmup) * args.passes_per_step * world
+
+    r = Renderer(scene, seed=args.seed, device_index=local_rank)
+    r.regenerate = bool(args.regenerate)
+    img = torch.zeros((r.n_pixels, 4), dtype=torch.float32, device='cuda')
+    r.use_image_buffer(img.data_ptr())
+
+    # one global tape (same seed on every rank); rank g renders passes g, g+N, g+2N, ...
+    P = args.passes_per_step
+    total = (args.steps + args.warmup) * P * world
+    tape = stripe(r.make_tape(0, total), rank, world)
+    r.upload_tape(tape)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for w in range(args.warmup):
+        r.render_resident(w * P, P)
+    if world > 1:
+        warm = img.clone()
+        dist.all_reduce(warm)          # set up the communicator outside the timed region
+    img.zero_()
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for k in range(args.steps):
+        kernel_ms.append(r.render_resident((args.warmup + k) * P, P))
+    if world > 1:
+        dist.all_reduce(img)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples = float(r.n_pixels) * P * args.steps * world
+    result = {
+        'metric': 'Msamples/sec (px*spp/s) on scene-dev', 'value': samples / elapsed / 1e6,
+        'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s %dx%d, %d sample passes per step (RGB, next-event light, '
+                               'max_bounces %d), broadcast random tape, parity build '
+                               '(-ffp-contract=off)' % (args.scene, width, height, P, scene.max_bounces),
+                   'passes_per_step': P, 'pixels': r.n_pixels,
+                   'parallelism': 'pass-striped x%d, one all-reduce' % world if world > 1 else 'single GPU'},
+    }
+    if rank == 0:
+        final = img.cpu().numpy()
+        assert np.isfinite(final).all() and final[:, :3].mean() > 0, "bad image"
+        result['image_mean'] = float(final[:, :3].mean() / (P * args.steps * world))
+        flops_per_sample = None
+        if world == 1 and not args.no_cpu_baseline:
+            base, flops_per_sample = cpu_baseline(r, tape, args.cpu_seconds)
+            result['cpu_baseline'] = base
+        avg_ms = float(np.mean(kernel_ms))
+        roof = {'bound': 'valu', 'kernel': 'clr_render', 'unit': 'TFLOP/s',
+                'peak': PEAK_FP32_VECTOR_TFLOPS, 'peak_unpacked_fma': PEAK_FP32_SCALAR_FMA_TFLOPS,
+                'kernel_ms_avg': avg_ms, 'traffic': None}
+        if flops_per_sample is not None:
+            achieved = flops_per_sample * r.n_pixels * P / (avg_ms * 1e-3) / 1e12
+            roof.update({'achieved': achieved, 'frac': achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         'frac_unpacked_fma': achieved / PEAK_FP32_SCALAR_FMA_TFLOPS,
+                         'flops_per_sample': flops_per_sample})
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc):
+            roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
+        result['roofline'] = roof
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

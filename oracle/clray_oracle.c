@@ -34,6 +34,10 @@ static __thread double orc_flops;
 
 #define PI_F 3.14159274101257324f
 
+/* exp, log, tan shared with the device code so that both sides produce the same bits */
+#define CLR_MATH_FN static inline
+#include "../raytracer_amd/hip_templates/clr_math.inl"
+
 /* ---- vector algebra, same definitions as hip_templates/static.hip ---- */
 static inline vec3 v3(float x, float y, float z) { vec3 v = {x, y, z}; return v; }
 static inline vec3 v3p(const float *p) { return v3(p[0], p[1], p[2]); }
@@ -501,7 +505,7 @@ static void qjs2_tracer(const orc_object *o, vec3 origin, vec3 ray, float old_is
             FL(8);
         }
         float l = sqrtf(dot4(q, q));
-        step = 0.5f * l * logf(l) / sqrtf(dot4(qd, qd));
+        step = 0.5f * l * clr_logf(l) / sqrtf(dot4(qd, qd));
         step = fminf(step, MAX_STEP);
         FL(8);
         (void)gr; (void)gi; (void)gj; (void)gk;
@@ -731,16 +735,16 @@ static int shade(const orc_scene *sc, const material_view *m, path_state *s, vec
         float last_dist = last_distance;
         const float alpha = mat_scalar(m, S_VOLUME_SCATTERING, s->inside);
         FL(1);
-        if (alpha > 0) { cur_prob = 1.0f - expf(-alpha * last_dist); FL(3); }
+        if (alpha > 0) { cur_prob = 1.0f - clr_expf(-alpha * last_dist); FL(3); }
         FL(1);
         if (p < cur_prob) {
-            float d = -logf(1.0f - p) / alpha;
+            float d = -clr_logf(1.0f - p) / alpha;
             FL(4);
             s->pos = sub3(s->pos, lscale3(last_dist - d, r));
             last_dist = d;
             s->whichobject = 0;
             const float blur = mat_scalar(m, S_VOLUME_SCATTERING_BLUR, s->inside);
-            if (blur < 1.0f) { FL(4); r = normalize3(add3(gauss_rvec, scale3(r, tanf(PI_F * 0.5f * (1.0f - blur))))); }
+            if (blur < 1.0f) { FL(4); r = normalize3(add3(gauss_rvec, scale3(r, clr_tanf(PI_F * 0.5f * (1.0f - blur))))); }
             else r = B->rvec;
             if (sc->bidirectional) s->suppress_emission = 0;
             p = -1.0f;
@@ -748,8 +752,8 @@ static int shade(const orc_scene *sc, const material_view *m, path_state *s, vec
         else { p -= cur_prob; FL(1); }
 
         cur_col = mat_color(m, M_VOLUME_ABSORPTION, s->inside);
-        if (rgb) { FL(6); pipeline_color = v3(expf(-cur_col.x * last_dist), expf(-cur_col.y * last_dist), expf(-cur_col.z * last_dist)); }
-        else { FL(2); float e = expf(-cur_col.x * last_dist); pipeline_color = v3(e, e, e); }
+        if (rgb) { FL(6); pipeline_color = v3(clr_expf(-cur_col.x * last_dist), clr_expf(-cur_col.y * last_dist), clr_expf(-cur_col.z * last_dist)); }
+        else { FL(2); float e = clr_expf(-cur_col.x * last_dist); pipeline_color = v3(e, e, e); }
         if (p < 0.0f) { s->ray = r; s->ray_color = mul3(s->ray_color, pipeline_color); }
     }
 

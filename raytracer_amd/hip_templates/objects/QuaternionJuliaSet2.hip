@@ -26,7 +26,7 @@
                 q = quaternion_square(q) + c;
             }
             float l = length(q);
-            step = 0.5f * l * logf(l) / length(qd);
+            step = 0.5f * l * clr_logf(l) / length(qd);
             step = fminf(step, MAX_STEP);
             if (step < TARGET_EPS) {
                 *t_hit = dist + step;

@@ -65,16 +65,16 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
     {
         float last_dist = last_distance;
         const float alpha = SCALAR(MAT_VOLUME_SCATTERING, s.inside);
-        if (alpha > 0) cur_prob = 1.0f - expf(-alpha*last_dist);
+        if (alpha > 0) cur_prob = 1.0f - clr_expf(-alpha*last_dist);
 
         if (p < cur_prob) {
             // scattering inside the medium at distance d < last_dist along the segment
-            float d = -logf(1.0f - p) / alpha;
+            float d = -clr_logf(1.0f - p) / alpha;
             s.pos -= (last_dist - d) * r;
             last_dist = d;
             s.whichobject = 0;
             const float blur = SCALAR(MAT_VOLUME_SCATTERING_BLUR, s.inside);
-            if (blur < 1.0f) r = normalize(gauss_rvec + r * tanf(CLR_PI_F*0.5f*(1.0f - blur)));
+            if (blur < 1.0f) r = normalize(gauss_rvec + r * clr_tanf(CLR_PI_F*0.5f*(1.0f - blur)));
             else r = B.rvec;
 ### if renderer.bidirectional
             s.suppress_emission = 0;
@@ -85,9 +85,9 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 
 ### if shader.rgb
         cur_col = COLOR(MAT_VOLUME_ABSORPTION, s.inside);
-        pipeline_color = make_vec3(expf(-cur_col.x*last_dist), expf(-cur_col.y*last_dist), expf(-cur_col.z*last_dist));
+        pipeline_color = make_vec3(clr_expf(-cur_col.x*last_dist), clr_expf(-cur_col.y*last_dist), clr_expf(-cur_col.z*last_dist));
 ### else
-        pipeline_color = expf(-SCALAR(MAT_VOLUME_ABSORPTION, s.inside)*last_dist);
+        pipeline_color = clr_expf(-SCALAR(MAT_VOLUME_ABSORPTION, s.inside)*last_dist);
 ### endif
         if (p < 0.0f) { s.ray = r; s.ray_color = s.ray_color * pipeline_color; }
     }

@@ -53,6 +53,9 @@ CLR_FN vec3 normalize(vec3 a) { return a / length(a); }
 #define fast_normalize normalize
 #define native_sqrt sqrtf
 
+#define CLR_MATH_FN CLR_FN
+{% include 'clr_math.inl' %}
+
 // ---- interval arithmetic (static.cl:4-61); an interval is (x = begin, y = end)
 typedef vec2 ia_type;
 #define ia_new(b, e) make_vec2(b, e)

@@ -42,7 +42,7 @@ class Renderer:
         extra = getattr(args, 'cl_build_options', None)
         if extra:
             self.build_options += extra.split()
-        self.regenerate = True
+        self.regenerate = False   # see main.hip: identical results, matters for per-pixel RNG
         self.acc = None
         if device:
             self.connect(device_index)
@@ -253,6 +253,7 @@ class Renderer:
             acc.set_global('clr_material_colors', self.material_colors)
             acc.set_global('clr_material_scalars', self.material_scalars)
         self._tape_capacity = 0
+        self.dev_rows = None
 
     def _upload_tape(self, tape):
         passes, bounces, rows = tape
@@ -267,6 +268,31 @@ class Renderer:
         self.dev_bounce_tape[:n].set(bounces)
         if rows is not None:
             self.dev_rows[:n].set(rows)
+
+    def use_image_buffer(self, device_ptr):
+        """Accumulate into caller-owned device memory (n_pixels x float4), e.g. a torch
+        tensor that takes part in an all-reduce."""
+        from .accelerator import DeviceArray
+        self.img = DeviceArray(self.acc, (self.n_pixels, 4), np.float32, ptr=int(device_ptr))
+
+    def upload_tape(self, tape):
+        """Make `tape` resident on the device; later launches pick pass ranges out of it."""
+        self._tape_capacity = 0
+        self._upload_tape(tape)
+        self._resident_passes = tape[0].shape[0]
+
+    def render_resident(self, first, count, stream=None, timed=True):
+        """Render passes [first, first + count) of the resident tape (no host transfer)."""
+        assert 0 <= first and first + count <= self._resident_passes
+        rows = self.dev_rows[first:first + count].ptr if self.dev_rows is not None else None
+        args = RenderArgs(
+            img=self.img.ptr, cam=self.cam.ptr,
+            pass_tape=self.dev_pass_tape[first:first + count].ptr,
+            bounce_tape=self.dev_bounce_tape[first:first + count].ptr, material_rows=rows,
+            vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
+            n_pixels=self.n_pixels, n_passes=count, regenerate=int(self.regenerate),
+            debug_dump=None)
+        return self.acc.render_passes(args, stream=stream, timed=timed)
 
     def render_tape(self, tape, debug=False, stream=None, timed=True):
         """Render the passes described by `tape` and add them to the image accumulator.

@@ -1,0 +1,31 @@
+import os
+import runpy
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCENE_DIR = os.path.join(ROOT, 'raytracer_amd', 'scenes')
+GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an AMD GPU (run on the MI355X box)")
+
+
+def load_scene(name, size=None, **overrides):
+    """A fresh copy of a shipped scene ('scene-dev', 'scene-three-objects', 'scene-test')."""
+    scene = runpy.run_path(os.path.join(SCENE_DIR, name + '.py'))['scene']
+    if size is not None:
+        scene.image.size = tuple(size)
+    for key, value in overrides.items():
+        setattr(scene, key, value)
+    return scene
+
+
+@pytest.fixture
+def scene_loader():
+    return load_scene

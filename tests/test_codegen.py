@@ -1,0 +1,44 @@
+"""Code generation: every shipped scene renders to one HIP translation unit that hiprtc
+compiles for gfx950 (no device needed), and the generator's de-duplication / clash rules."""
+import pytest
+
+from raytracer_amd import accelerator, hip_compiler
+from raytracer_amd.renderer import Renderer
+from raytracer_amd import objects as shapes
+from conftest import load_scene
+
+
+@pytest.mark.parametrize('name', ['scene-dev', 'scene-three-objects', 'scene-test'])
+def test_scene_program_compiles_for_gfx950(name):
+    r = Renderer(load_scene(name, (64, 48)), device=False, seed=0)
+    code = r.program_code
+    assert 'extern "C" __global__' in code and 'clr_render' in code and 'clr_first_hit' in code
+    assert accelerator.compile_only(code, r.build_options, 'gfx950') > 10000
+
+
+def test_one_function_per_class_not_per_instance():
+    r = Renderer(load_scene('scene-test', (16, 8)), device=False, seed=0)
+    code = r.program_code
+    # two Octahedron instances share one tracer; the two generic ConvexIntersections do not
+    assert code.count('void Octahedron_tracer(') == 2          # declaration + definition
+    assert 'ConvexIntersection_CylinderComponent_SphereComponent_LayerComponent_tracer' in code
+    assert code.count('void LayerComponent_tracer(') == 2
+
+
+def test_name_clash_is_an_error():
+    class Impostor(shapes.Sphere):
+        def template_name(self):
+            return 'HalfSpace'
+
+        @property
+        def tracer_function_name(self):
+            return 'Sphere_tracer'
+
+    scene = load_scene('scene-dev', (16, 8))
+    scene.add_object(Impostor((0, 0, 0), 1.0), 'white')
+    with pytest.raises(RuntimeError):
+        Renderer(scene, device=False, seed=0)
+
+
+def test_parity_options_disable_contraction():
+    assert '-ffp-contract=off' in hip_compiler.PARITY_OPTIONS

@@ -1,0 +1,199 @@
+"""Host-side scene API: the reference's own unit tests (tests.py:11-88, TestAffine) restated
+for this package, plus the packing helpers the renderer relies on."""
+import io
+
+import numpy as np
+import pytest
+
+from raytracer_amd import camera, mesh_formats, transformations
+from raytracer_amd.transformations import Affine
+from raytracer_amd.renderer import Renderer
+from raytracer_amd import objects as shapes
+from conftest import load_scene
+
+EPSILON = 1e-9
+
+
+def close(a, b):
+    return np.linalg.norm(np.ravel(a) - np.ravel(b)) < EPSILON
+
+
+class TestAffine:
+    rng = np.random.RandomState(7)
+
+    def test_identity(self):
+        vec = self.rng.normal(size=3)
+        t = Affine.identity()
+        assert close(vec, t(vec))
+        assert t.is_identity()
+        assert not Affine(translation=(1, 2, 3)).is_identity()
+        assert not Affine(rotation_axis='y', rotation_deg=10).is_identity()
+        ccw = Affine(rotation_axis=(1, 0, 0), rotation_deg=90)
+        cw = Affine(rotation_axis='x', rotation_deg=-90)
+        assert ccw(cw).is_identity()
+
+    def test_translation(self):
+        t = Affine(translation=(1, 2, 3))
+        assert close(t((0, -1, -3)), (1, 1, 0))
+        assert close(t * (0, -1, -3), (1, 1, 0))
+
+    def test_inverse(self):
+        t = Affine(linear=self.rng.normal(size=(3, 3)), translation=self.rng.normal(size=3))
+        assert t.inverse()(t).is_identity()
+        assert (t.inverse() * t).is_identity()
+
+    def test_roto_translation(self):
+        t = Affine(rotation_axis='z', rotation_deg=90, translation=(2, 0, 0))
+        assert close(t((1, 0, 0)), (2, 1, 0))
+
+    def test_scaling(self):
+        assert close(Affine(scaling=(1, 2, 3))((1, 1, 1)), (1, 2, 3))
+        assert close(Affine(scaling=10)((1, 2, 3)), (10, 20, 30))
+
+    def test_orthogonality(self):
+        assert Affine.identity().is_orthogonal()
+        assert Affine(rotation_axis=self.rng.normal(size=3),
+                      rotation_deg=self.rng.rand() * 360).is_orthogonal()
+        assert not Affine(scaling=2.0).is_orthogonal()
+
+    def test_rotation_aligning_vectors(self):
+        mat = transformations.rotation_aligning_vectors((2, 0, 0), (0, 3, 0))
+        assert close(mat @ np.array((2, 0, 0)), (0, 2, 0))
+        assert Affine(linear=transformations.rotation_aligning_vectors((2, 0, 0), (2, 0, 0))).is_identity()
+
+
+def test_image_order_matches_reference_loop_nest():
+    """renderer.py:438-448 (the reference's `width` is the image height)."""
+    r = Renderer(load_scene('scene-dev', (16, 24)), device=False, seed=0)
+    rows, cols = r.img_shape
+    expected = []
+    for col_block in range(cols // 4):
+        for row_block in range(rows // 8):
+            for in_col in range(4):
+                for in_row in range(8):
+                    expected.append([in_row + row_block * 8, in_col + col_block * 4])
+    assert np.array_equal(r.image_order, np.array(expected))
+    # every pixel exactly once
+    flat = r.image_order[:, 0] * cols + r.image_order[:, 1]
+    assert np.array_equal(np.sort(flat), np.arange(rows * cols))
+
+
+def test_image_order_fallback_for_ragged_sizes():
+    r = Renderer(load_scene('scene-dev', (6, 10)), device=False, seed=0)
+    assert r.image_order.shape == (60, 2)
+    assert np.array_equal(r.image_order[:7, 1], [0, 1, 2, 3, 4, 5, 0])
+
+
+def test_object_grouping_and_ids():
+    r = Renderer(load_scene('scene-dev', (16, 8)), device=False, seed=0)
+    names = [o.tracer.tracer_kernel_name for o in r.scene.objects]
+    assert names == sorted(names)
+    assert [(t.__class__.__name__, c, o) for t, c, o in r.object_groups] == \
+        [('HalfSpace', 7, 0), ('Sphere', 2, 7)]
+    assert r.bidirectional and r.bidirectional_light_ids == [7]
+    # 4 affine slots per object, no declared parameters for these classes
+    assert r.param_table.shape == (9 * 4, 4)
+
+
+def test_parameter_table_holds_inverse_affine():
+    r = Renderer(load_scene('scene-three-objects', (16, 8)), device=False, seed=0)
+    for obj, base in zip(r.scene.objects, r.object_param_base):
+        n_decl = len(obj.tracer.parameter_types())
+        inv = obj.tracer.global_to_tracer_coordinate_transform().inverse()
+        rows = r.param_table[base + n_decl: base + n_decl + 4, :3]
+        assert np.allclose(rows[:3], inv.linear, rtol=1e-6, atol=1e-7)
+        assert np.allclose(rows[3], inv.translation, rtol=1e-6, atol=1e-7)
+
+
+def test_material_tables_are_property_major():
+    r = Renderer(load_scene('scene-dev', (16, 8)), device=False, seed=0)
+    n = len(r.scene.objects) + 1
+    offsets = dict(r.shader.get_material_property_offsets())
+    assert offsets['DIFFUSE'] == 0 and offsets['EMISSION'] == n and offsets['IOR'] == 0
+    light_id = r.bidirectional_light_ids[0] + 1
+    assert np.allclose(r.material_colors[offsets['EMISSION'] + light_id, :3], (4, 2, .7))
+    assert np.allclose(r.material_colors[offsets['DIFFUSE'] + 0, :3], (1, 0, 1))     # ambient
+    assert r.material_scalars[offsets['IOR'] + 0] == 1.0
+
+
+def test_tape_is_deterministic_and_ordered():
+    a = Renderer(load_scene('scene-dev', (16, 8)), device=False, seed=3).make_tape(0, 4)
+    b = Renderer(load_scene('scene-dev', (16, 8)), device=False, seed=3).make_tape(0, 4)
+    for x, y in zip(a[:2], b[:2]):
+        assert np.array_equal(x, y)
+    passes, bounces, rows = a
+    assert rows is None
+    assert np.allclose(np.linalg.norm(bounces[:, :, 0, :3], axis=-1), 1.0, atol=1e-6)   # unit rvec
+    assert np.all((bounces[:, :, 0, 3] >= 0) & (bounces[:, :, 0, 3] < 1))                 # p
+    light_ids = bounces[:, :, 4, 3].view(np.int32)
+    assert np.all(light_ids[:, :-1] == 8) and np.all(light_ids[:, -1] == 0)               # 0 on last
+
+
+def test_read_off_and_dedupe():
+    text = "OFF\n4 2 0\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n3 0 2 1\n"
+    vertices, faces = mesh_formats.read_off(io.StringIO(text))
+    assert len(vertices) == 4 and faces == [[0, 1, 2], [0, 2, 3], [0, 2, 1]]
+    assert mesh_formats.remove_duplicate_faces(faces) == [[0, 1, 2], [0, 2, 3]]
+    with pytest.raises(RuntimeError):
+        mesh_formats.read_off(io.StringIO("PLY\n"))
+
+
+def test_read_zipper():
+    text = ("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nelement face 1\n"
+            "end_header\n0 0 0 0.5\n1 0 0 0.5\n0 1 0 0.5\n3 0 1 2\n")
+    vertices, faces = mesh_formats.read_zipper(io.StringIO(text))
+    assert vertices == [[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]] and faces == [[0, 1, 2]]
+
+
+def random_triangle_soup(n, seed=0, size=0.08):
+    rng = np.random.RandomState(seed)
+    centers = rng.uniform(-1, 1, (n, 1, 3))
+    vertices = (centers + rng.normal(0, size, (n, 3, 3))).reshape(-1, 3)
+    return vertices, np.arange(3 * n).reshape(n, 3)
+
+
+@pytest.mark.parametrize('source', ['scene-test', 'soup'])
+def test_octree_stream_is_self_consistent(source):
+    if source == 'scene-test':
+        scene = load_scene('scene-test', (16, 8))
+        octree = [o.tracer for o in scene.objects if isinstance(o.tracer, shapes.Octree)][0]
+    else:
+        vertices, faces = random_triangle_soup(400)
+        octree = shapes.Octree(shapes.TriangleMesh(vertices, faces), max_depth=4)
+    data = octree.get_data()['integer']
+    n_faces = octree.total_faces
+    assert np.array_equal(data[:3 * n_faces], np.ravel(octree.triangle_mesh.faces))
+    tree = data[3 * n_faces:]
+    mask, ptr = tree[octree.root_data_offset], tree[octree.root_data_offset + 1]
+    if source == 'soup':
+        assert mask not in (0, 0x100)      # 400 small faces force splits
+        assert len(octree.leaves) > 8
+    seen_faces = set()
+
+    def walk(mask, ptr, depth):
+        if mask == 0x100:
+            return
+        if mask == 0:
+            n = tree[ptr]
+            seen_faces.update(int(f) for f in tree[ptr + 1: ptr + 1 + n])
+            return
+        assert depth < octree.max_depth + 1
+        for child in range(8):
+            walk(tree[ptr + 2 * child], tree[ptr + 2 * child + 1], depth + 1)
+    walk(mask, ptr, 0)
+    assert seen_faces == set(range(n_faces))
+
+
+def test_cube_without_size_is_an_error_like_the_reference():
+    with pytest.raises(TypeError):
+        shapes.Cube((0, 0, 0))
+
+
+def test_camera_helpers():
+    rot = camera.camera_rotmat((0, 1, 0), (0, 0, 1))
+    assert np.allclose(rot.T @ rot, np.eye(3), atol=1e-12)
+    rays = camera.camera_rays((8, 4), False, 60, (0, 1, 0), (0, 0, 1))
+    assert rays.shape == (4, 8, 3)
+    assert np.allclose(np.linalg.norm(rays, axis=-1), 1.0)
+    q = camera.quasi_random_direction_sample(10)
+    assert q.shape == (10, 3) and np.all(q[:, 2] > 0)
