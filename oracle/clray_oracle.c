@@ -948,12 +948,11 @@ static int segment(const orc_scene *sc, const material_view *m, path_state *s, c
     if (sc->bidirectional && !is_last)
         shadow_mask = light_visibility(sc, s->pos, normal, whichobject, which_subobject, s->inside,
                                        s->diffusions_left, B->light_point, B->light_id);
-    const vec3 hit_pos = s->pos;
     const int alive = shade(sc, m, s, normal, isec_dist, shadow_mask, B, is_last, cmask, img);
     if (dbg) {
         put4(dbg, as_float((int)whichobject), as_float((int)which_subobject), as_float((int)s->inside), as_float(s->diffusions_left));
         put4(dbg + 4, isec_dist, alive ? 1.0f : 0.0f, shadow_mask, as_float(s->suppress_emission));
-        put4(dbg + 8, hit_pos.x, hit_pos.y, hit_pos.z, 0.0f);
+        put4(dbg + 8, s->pos.x, s->pos.y, s->pos.z, as_float((int)s->whichobject));
         put4(dbg + 12, s->ray.x, s->ray.y, s->ray.z, 0.0f);
         put4(dbg + 16, normal.x, normal.y, normal.z, 0.0f);
         put4(dbg + 20, s->ray_color.x, s->ray_color.y, s->ray_color.z, 0.0f);

@@ -146,7 +146,6 @@ CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last,
         shadow_mask = clr_light_visibility(s.pos, normal, whichobject, which_subobject, s.inside,
             s.diffusions_left, B.light_point, B.light_id, vector_data, integer_data);
 ### endif
-    const vec3 hit_pos = s.pos;
     const bool alive = clr_shade(s, normal, isec_dist, shadow_mask, B, is_last, cmask, img
 ### if not shader.rgb
         , material_row
@@ -156,7 +155,8 @@ CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last,
         dbg[0] = make_float4(__int_as_float((int)whichobject), __int_as_float((int)which_subobject),
                              __int_as_float((int)s.inside), __int_as_float(s.diffusions_left));
         dbg[1] = make_float4(isec_dist, alive ? 1.0f : 0.0f, shadow_mask, __int_as_float(s.suppress_emission));
-        dbg[2] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, 0.0f);
+        // state after shading: position (moved back on volume scattering), surface id (0 then)
+        dbg[2] = make_float4(s.pos.x, s.pos.y, s.pos.z, __int_as_float((int)s.whichobject));
         dbg[3] = make_float4(s.ray.x, s.ray.y, s.ray.z, 0.0f);
         dbg[4] = make_float4(normal.x, normal.y, normal.z, 0.0f);
         const vec3 c = color_to_rgb(s.ray_color, make_vec3(1.0f, 1.0f, 1.0f));

@@ -198,9 +198,14 @@ class Renderer:
         return ((light_id, tracer.surface_area()) + tracer.random_surface_point_and_normal(self.rng)
                 + tracer.center_and_min_sampling_distance())
 
-    def make_tape(self, first_pass, n_passes):
+    def make_tape(self, first_pass, n_passes, segments=None):
         """Draw the random numbers of `n_passes` passes in the reference's order (SURVEY
-        Appendix B) and lay them out for the device."""
+        Appendix B) and lay them out for the device.
+
+        The reference stops drawing for a pass once no ray of the frame is alive
+        (renderer.py:318-320, 430), which only happens at very small frame sizes; this
+        generator always draws all max_bounces segments unless `segments[j]` gives the number
+        of segments the reference executed in pass j (used to replay recorded tapes)."""
         scene = self.scene
         max_bounces = scene.max_bounces
         passes = np.zeros((n_passes, PASS_RECORD, 4), dtype=np.float32)
@@ -218,7 +223,7 @@ class Renderer:
                 inv_pdf, rows[j], cmask = self.shader.sample_wavelength(self.rng.random_sample())
                 passes[j, 4, 3] = inv_pdf
                 passes[j, 5, 0:3] = cmask
-            for b in range(max_bounces):
+            for b in range(max_bounces if segments is None else int(segments[j])):
                 is_last = b == max_bounces - 1
                 rec = bounces[j, b]
                 if self.bidirectional:

@@ -124,3 +124,38 @@ def test_bad_arguments_are_rejected():
     r = Renderer(load_scene('scene-dev', (32, 16)), seed=0)
     with pytest.raises(ClrError):
         r.acc.render_passes(RenderArgs(n_pixels=10, n_passes=1))
+
+
+@pytest.mark.parametrize('name', SCENES)
+def test_hip_against_reference_golden(name):
+    """HIP directly against the fixtures made from the reference's own device code
+    (tests/test_golden.py explains the fixtures and the bars)."""
+    import os
+    from conftest import GOLDEN_DIR
+    from test_golden import flat_octree_ids, near
+    fx = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    size = tuple(int(v) for v in fx['size'])
+    r = Renderer(load_scene(name, size, samples_per_pixel=4), seed=int(fx['seed']))
+    assert np.array_equal(r.host_cam, fx['cam'])
+    tape = (fx['pass_tape'][:1], fx['bounce_tape'][:1], None)
+    ids, t, normal = r.first_hit(tape)
+    pixel = fx['seg0_pixel'].astype(np.int64)
+    post = fx['seg0_whichobject'].astype(np.int32)
+    hit = post != 0
+    assert np.array_equal(ids[pixel, 0][hit], post[hit])                      # ids: bit-exact
+    assert np.array_equal(ids[pixel, 1][hit], fx['seg0_which_subobject'].astype(np.int32)[hit])
+    t_ref = fx['seg0_isec_dist']
+    assert np.all(np.abs(t[pixel] - t_ref) <= 1e-4 * np.abs(t_ref))           # t: 1e-4 relative
+    # image after all recorded passes, per-channel relative RMSE 1e-4
+    img = np.zeros((r.n_pixels, 4), np.float32)
+    tainted = np.zeros(r.n_pixels, bool)
+    for j in range(int(fx['n_passes'])):
+        _, dump = r.render_tape((fx['pass_tape'][j:j + 1], fx['bounce_tape'][j:j + 1], None), debug=True)
+        tainted |= np.isin(dump[:, :, 0, 0].view(np.int32), flat_octree_ids(r)).any(axis=0)
+    img = r.img.get()
+    ref = fx['img'][~tainted, :3].astype(np.float64)
+    got = img[~tainted, :3].astype(np.float64)
+    for c in range(3):
+        rmse = np.sqrt(np.mean((got[:, c] - ref[:, c]) ** 2))
+        assert rmse <= 1e-4 * max(np.sqrt(np.mean(ref[:, c] ** 2)), 1e-12), (c, rmse)
+    assert near(got, ref, 1e-4).all()

@@ -1,0 +1,387 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the reference's OWN code.
+
+Runs only in the development container (it reads /root/reference, which never travels to
+the GPU box).  Nothing of the reference is copied into the repository: the script
+
+  1. makes a temporary Python 3 conversion of the reference under /tmp (lib2to3, plus the
+     three integer divisions Python 3 changed), with a stub for the absent `pyopencl` import;
+  2. lets the reference's own Renderer / Compiler / scene files pack a scene and render its
+     OpenCL program text (the Jinja2 templates of the reference);
+  3. compiles that OpenCL C for x86-64 with ROCm's clang (-O1, -ffp-contract=off), links it
+     with a small shim defining the OpenCL built-ins it uses (dot, cross, length, normalize,
+     native_sqrt, get_global_id, ...) and per-kernel trampolines;
+  4. substitutes a numpy-backed Accelerator so that the reference's own render loop
+     (Renderer.render_sample / compute_next_path_segment) drives those kernels, with
+     np.random seeded;
+  5. records what went in (camera rays, random numbers as uploaded, packed scene tables) and
+     what came out (per-segment ray state of the first pass, image sums) as .npz.
+
+Two patches are applied in the temporary copy and recorded in the fixture metadata:
+  * with warp_size 1 the reference's culler reads `max_value` uninitialised; it
+    is initialised to the ray's own intensity, which is what the warp reduction computes for
+    a group of one ray;
+  * ConvexIntersection.cl accumulates the sub-object offset with `set` inside a Jinja2 for
+    loop, which Jinja2 < 2.9 carried across iterations and the installed 3.1 does not (every
+    component would get offset 0 and the last component's normal would always win); the
+    running offset is kept in a namespace object instead, restoring the intended output.
+
+Usage:  python tools/make_golden.py [scene-dev scene-three-objects scene-test]
+"""
+import ctypes
+import os
+import re
+import shutil
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+REFERENCE = '/root/reference'
+WORK = '/tmp/clray_golden'
+REF3 = os.path.join(WORK, 'ref3')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, 'tests', 'golden')
+CLANG = '/opt/rocm/lib/llvm/bin/clang'
+
+SHIM = r'''
+// OpenCL C built-ins used by the reference's kernels, for the x86-64 build of its device code.
+#include <cmath>
+typedef float float2 __attribute__((ext_vector_type(2)));
+typedef float float3 __attribute__((ext_vector_type(3)));
+typedef float float4 __attribute__((ext_vector_type(4)));
+typedef int int3 __attribute__((ext_vector_type(3)));
+typedef unsigned int uint;
+static thread_local uint gid[3];
+extern "C" void shim_set_gid(uint i, uint j) { gid[0] = i; gid[1] = j; gid[2] = 0; }
+uint get_global_id(uint d) { return gid[d]; }
+uint get_local_id(uint d) { return 0; }
+void barrier(uint) {}
+float native_sqrt(float x) { return sqrtf(x); }
+float sqrt(float x) { return sqrtf(x); }
+float exp(float x) { return expf(x); }
+float log(float x) { return logf(x); }
+float tan(float x) { return tanf(x); }
+float max(float a, float b) { return fmaxf(a, b); }
+float min(float a, float b) { return fminf(a, b); }
+float clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+float dot(float3 a, float3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+float dot(float2 a, float2 b) { return a.x*b.x + a.y*b.y; }
+float dot(float4 a, float4 b) { return a.x*b.x + a.y*b.y + a.z*b.z + a.w*b.w; }
+float3 cross(float3 a, float3 b) { return (float3){a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x}; }
+float length(float3 a) { return sqrtf(dot(a, a)); }
+float length(float4 a) { return sqrtf(dot(a, a)); }
+float3 normalize(float3 a) { return a / length(a); }
+float3 fast_normalize(float3 a) { return a / length(a); }
+float3 convert_float3(int3 a) { return (float3){(float)a.x, (float)a.y, (float)a.z}; }
+int all(int3 a) { return (a.x < 0) && (a.y < 0) && (a.z < 0); }
+int3 isfinite(float3 a) { return (int3){std::isfinite(a.x) ? -1 : 0, std::isfinite(a.y) ? -1 : 0, std::isfinite(a.z) ? -1 : 0}; }
+'''
+
+
+def sh(*cmd, **kw):
+    subprocess.check_call(list(cmd), **kw)
+
+
+def prepare_reference():
+    """Temporary Python 3 copy of the reference + pyopencl stub (never committed)."""
+    if os.path.exists(os.path.join(REF3, '.converted')):
+        return
+    shutil.rmtree(REF3, ignore_errors=True)
+    os.makedirs(WORK, exist_ok=True)
+    shutil.copytree(REFERENCE, REF3)
+    sh(sys.executable, '-m', 'lib2to3', '-w', '-n', '.', cwd=REF3,
+       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def patch(path, old, new):
+        p = os.path.join(REF3, path)
+        text = open(p).read()
+        assert old in text, (path, old)
+        open(p, 'w').write(text.replace(old, new))
+    patch('camera.py', 'n = n/2', 'n = n//2')
+    patch('renderer.py', 'range(height / block_h)', 'range(height // block_h)')
+    patch('renderer.py', 'range(width / block_w)', 'range(width // block_w)')
+    # Jinja2 >= 2.9 no longer carries `set` assignments from one loop iteration to the next;
+    # the reference's running sub-object offset (ConvexIntersection.cl:11,37,54,65) relies on
+    # the pre-2.9 behaviour.  Restore it in the temporary copy with a namespace object.
+    p = os.path.join(REF3, 'cl_templates', 'objects', 'ConvexIntersection.cl')
+    text = open(p).read()
+    assert text.count('### set subobj_offset = 0') == 2
+    text = text.replace('### set subobj_offset = 0', '### set ns = namespace(off=0)')
+    text = text.replace('### set subobj_offset = subobj_offset + component.n_subobjects',
+                        '### set ns.off = ns.off + component.n_subobjects')
+    text = text.replace('subobj_offset', 'ns.off')
+    open(p, 'w').write(text)
+    stub = os.path.join(REF3, 'pyopencl')
+    os.makedirs(stub)
+    open(os.path.join(stub, '__init__.py'), 'w').write(
+        "VERSION = (2016, 2)\nclass mem_flags:\n    READ_ONLY = 1\n    COPY_HOST_PTR = 2\n    READ_WRITE = 4\n")
+    open(os.path.join(stub, 'array.py'), 'w').write("class Array(object):\n    pass\n")
+    open(os.path.join(stub, 'tools.py'), 'w').write("")
+    open(os.path.join(REF3, '.converted'), 'w').write('ok')
+
+
+class HostArray(np.ndarray):
+    """numpy array with the two pyopencl Array methods the reference uses."""
+    def get(self):
+        return np.array(self)
+
+
+def as_host(a):
+    return np.ascontiguousarray(a).view(HostArray)
+
+
+class FakeAccelerator:
+    """numpy-backed stand-in for the reference's pyopencl Accelerator; kernels are the
+    reference's OpenCL C compiled for the host."""
+    warp_size = 1
+
+    def __init__(self, *args):
+        self.lib = None
+        self.profiling_info = {}
+        self.trace = []            # (kernel_name, value_args snapshot)
+        self.hooks = []
+
+    def finish(self):
+        pass
+
+    def build_program(self, prog_code, options=[]):
+        if isinstance(prog_code, bytes):
+            prog_code = prog_code.decode('ascii')
+        old = "float max_value;\n    scratch[local_idx] = cur_intensity;"
+        assert old in prog_code
+        prog_code = prog_code.replace(old, "float max_value = cur_intensity;\n    scratch[local_idx] = cur_intensity;")
+        self.source = prog_code
+        tag = '%08x' % (hash(prog_code) & 0xffffffff)
+        d = os.path.join(WORK, 'build_' + tag)
+        os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, 'scene.cl'), 'w').write(prog_code)
+        # kernel signatures -> trampolines that loop over the ND-range
+        self.kernels = {}
+        tramp = ['typedef unsigned int uint;', 'extern "C" void shim_set_gid(uint, uint);']
+        for m in re.finditer(r'__kernel\s+void\s+(\w+)\s*\((.*?)\)\s*\{', prog_code, re.S):
+            name, params = m.group(1), re.sub(r'//[^\n]*', '', m.group(2))
+            kinds = []
+            for p in params.split(','):
+                p = p.strip()
+                kinds.append('ptr' if '*' in p else ('float' if re.search(r'\bfloat\b', p) else 'int'))
+            self.kernels[name] = kinds
+            ctype = {'ptr': 'void*', 'float': 'float', 'int': 'int'}
+            decl = ', '.join('%s a%d' % (ctype[k], i) for i, k in enumerate(kinds))
+            call = ', '.join('a%d' % i for i in range(len(kinds)))
+            tramp.append('extern "C" void %s(%s);' % (name, decl))
+            tramp.append('extern "C" void run_%s(int n0, int n1, %s) { for (int j = 0; j < n1; ++j) '
+                         'for (int i = 0; i < n0; ++i) { shim_set_gid(i, j); %s(%s); } }' % (name, decl, name, call))
+        open(os.path.join(d, 'tramp.cpp'), 'w').write('\n'.join(tramp))
+        open(os.path.join(d, 'shim.cpp'), 'w').write(SHIM)
+        flags = ['-O1', '-ffp-contract=off', '-fPIC']
+        sh(CLANG, '-x', 'cl', '-cl-std=CL1.2', '-Xclang', '-finclude-default-header',
+           '-target', 'x86_64-unknown-linux-gnu', '-w', *flags, '-c', 'scene.cl', '-o', 'scene.o', cwd=d)
+        sh(CLANG + '++', *flags, '-c', 'shim.cpp', '-o', 'shim.o', cwd=d)
+        sh(CLANG + '++', *flags, '-c', 'tramp.cpp', '-o', 'tramp.o', cwd=d)
+        sh(CLANG + '++', '-shared', 'scene.o', 'shim.o', 'tramp.o', '-o', 'refdev.so', cwd=d)
+        undefined = subprocess.check_output(['nm', '-u', os.path.join(d, 'refdev.so')]).decode()
+        missing = [l for l in undefined.splitlines() if '_Z' in l and 'GLIBC' not in l and 'CXXABI' not in l]
+        assert not missing, missing
+        self.lib = ctypes.CDLL(os.path.join(d, 'refdev.so'))
+        return self.lib
+
+    def call(self, kernel_name, ndrange_size, buffer_args, value_args=tuple([]), work_group_size=None):
+        if isinstance(ndrange_size, (int, np.integer)):
+            ndrange_size = (int(ndrange_size), 1)
+        for hook in self.hooks:
+            hook(kernel_name, ndrange_size, buffer_args, value_args)
+        kinds = self.kernels[kernel_name]
+        args = list(buffer_args) + list(value_args)
+        assert len(args) == len(kinds), (kernel_name, len(args), len(kinds))
+        conv = []
+        for a, k in zip(args, kinds):
+            if k == 'ptr':
+                assert a is None or isinstance(a, np.ndarray), (kernel_name, type(a))
+                conv.append(ctypes.c_void_p(None if a is None else a.ctypes.data))
+            elif k == 'float':
+                conv.append(ctypes.c_float(float(a)))
+            else:
+                conv.append(ctypes.c_int(int(a)))
+        fn = getattr(self.lib, 'run_' + kernel_name)
+        fn.restype = None
+        fn(ctypes.c_int(int(ndrange_size[0])), ctypes.c_int(int(ndrange_size[1])), *conv)
+
+    def enqueue_copy(self, dest, src):
+        np.copyto(dest.reshape(-1)[:np.size(src)], np.ravel(src).astype(dest.dtype))
+
+    def to_device(self, cpuarray):
+        return as_host(np.array(cpuarray))
+
+    def new_array(self, shape, datatype=np.float32, zeros=False):
+        return as_host(np.zeros(shape, dtype=datatype))
+
+    def new_const_buffer(self, buf, dtype=np.float32):
+        return as_host(np.array(buf).astype(dtype))
+
+    def new_vec3_array(self, shape):
+        return as_host(np.zeros(tuple(shape) + (4,), dtype=np.float32))
+
+    def _host_vec3(self, a):
+        out = np.zeros(a.shape[:-1] + (4,), dtype=np.float32)
+        out[..., :3] = a
+        return out
+
+    def make_vec3_array(self, a):
+        return as_host(self._host_vec3(a))
+
+    make_const_vec3_buffer = make_vec3_array
+
+    def empty_like(self, a):
+        return as_host(np.zeros_like(a))
+
+    zeros_like = empty_like
+
+    def find_non_negative(self, in_array, out_array, n):
+        # stable copy-if over `__global int *` views, as pyopencl's GenericScanKernel does it
+        signed = np.asarray(in_array[:n]).view(np.int32)
+        keep = signed[signed >= 0]
+        np.asarray(out_array).view(np.int32)[:keep.size] = keep
+        return int(keep.size)
+
+    def output_profiling_info(self):
+        pass
+
+
+def import_reference():
+    prepare_reference()
+    for p in (REF3, os.path.join(REF3, 'objects'), os.path.join(REF3, 'scenes')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    np.set_printoptions(legacy='1.25')       # numpy-2 scalar reprs would leak into the OpenCL text
+    import jinja2
+    jinja2.PackageLoader = lambda *a, **k: jinja2.FileSystemLoader(os.path.join(REF3, 'cl_templates'))
+    import renderer as ref_renderer
+    ref_renderer.Accelerator = FakeAccelerator
+    return ref_renderer
+
+
+def make_fixture(scene_name, size, n_passes, seed):
+    ref_renderer = import_reference()
+    np.random.seed(seed)
+    for mod in [m for m in sys.modules if m == scene_name]:
+        del sys.modules[mod]
+    scene = __import__(scene_name).scene
+    scene.image.size = size
+    scene.samples_per_pixel = max(n_passes, 4)
+    args = types.SimpleNamespace(choose_opencl_context=False, cl_build_options=[])
+    r = ref_renderer.Renderer(scene, args)
+    acc = r.acc
+    n_pixels = r.n_pixels
+    max_bounces = scene.max_bounces
+
+    # ---- inputs as the device sees them
+    fx = {
+        'size': np.array(size), 'seed': np.array(seed), 'n_passes': np.array(n_passes),
+        'object_names': np.array([o.tracer.tracer_kernel_name for o in scene.objects]),
+        'cam': np.array(r.cam), 'image_order': np.array(r.image_order),
+        'root_object_id': np.array(r.root_object_id),
+        'bidirectional_light_ids': np.array(r.bidirectional_light_ids),
+        'data_pointer_offset': np.array(r.object_data_pointer_buffer_offset),
+        'material_colors': np.array(r.shader.material_buffers[0]),
+        'material_scalars': np.array(r.shader.material_buffers[1]),
+        'patch': np.array('culler: float max_value = cur_intensity (SURVEY F12); '
+                          'ConvexIntersection.cl: running sub-object offset kept in a jinja2 '
+                          'namespace (pre-2.9 loop scoping)'),
+    }
+    for key, buf in zip(['vector', 'integer'], r.tracer_data_buffers):
+        if buf is not None:
+            fx['data_' + key] = np.array(buf)
+    for key, buf in zip(['param_float3', 'param_int', 'param_float'], r.tracer_const_data_buffers):
+        if buf is not None:
+            fx[key] = np.array(buf)
+
+    # ---- record the random numbers as uploaded, per pass and per segment
+    pass_tape = np.zeros((n_passes, 6, 4), np.float32)
+    bounce_tape = np.zeros((n_passes, max_bounces, 5, 4), np.float32)
+    state = {'pass': -1, 'segment': -1}
+    snapshots = []
+
+    def hook(name, ndrange, buffer_args, value_args):
+        j, b = state['pass'], state['segment']
+        if name == 'subsample_transform_camera':
+            pass_tape[j, 0:4, :] = value_args[0][:4]
+        elif name == 'fill_vec_broadcast':
+            pass_tape[j, 4, 0:3] = value_args[0][0, :3]
+            pass_tape[j, 4, 3] = 1.0
+            pass_tape[j, 5, 0:3] = 1.0
+        elif name == 'shader_volumetric':
+            rec = bounce_tape[j, b]
+            vb = value_args[-1]
+            rec[0, 0:3] = vb[0, :3]
+            rec[0, 3] = buffer_args[1][0]            # the shared stage sample p
+            rec[1, 0:3] = vb[1, :3]
+            if r.bidirectional:
+                light_id1, light_area, min_dist = value_args[0], value_args[1], value_args[2]
+                rec[2, 0:3], rec[2, 3] = vb[3, :3], light_area
+                rec[3, 0:3], rec[3, 3] = vb[4, :3], min_dist
+                rec[4, 0:3] = vb[5, :3]
+                rec[4, 3:4] = np.array([light_id1], np.int32).view(np.float32)
+        elif name == 'culler':
+            bounce_tape[j, b, 1, 3] = value_args[0]
+    acc.hooks.append(hook)
+
+    # ---- wrap the per-segment method to snapshot the ray state of pass 0
+    original = r.compute_next_path_segment
+
+    def wrapped(sample_index, path_index, is_last):
+        state['segment'] = path_index
+        n = r.cur_n_pixels
+        pixel_before = np.array(r.ray_state.pixel[:n])
+        ok = original(sample_index, path_index, is_last)
+        if state['pass'] == 0:
+            rs = r.ray_state
+            snap = {'n': n, 'pixel': pixel_before}
+            # thread-indexed scratch -> gather as is; ray-indexed state -> index by pixel
+            for key in ('isec_dist', 'normal', 'prob'):
+                snap[key] = np.array(getattr(rs, key)[:n])
+            if r.bidirectional:
+                snap['shadow_mask'] = np.array(rs.shadow_mask[:n])
+                snap['suppress_emission'] = np.array(rs.suppress_emission)[pixel_before]
+            for key in ('whichobject', 'which_subobject', 'pos', 'ray', 'raycolor', 'inside', 'diffusions_left'):
+                snap[key] = np.array(getattr(rs, key))[pixel_before]
+            alive = np.zeros(n_pixels, bool)
+            if not is_last:
+                alive[np.array(rs.pixel[:r.cur_n_pixels])] = True
+            snap['alive'] = alive[pixel_before]
+            snap['img'] = np.array(r.img)
+            snapshots.append(snap)
+        return ok
+    r.compute_next_path_segment = wrapped
+
+    images = []
+    for j in range(n_passes):
+        state['pass'] = j
+        r.render_sample(j)
+        images.append(np.array(r.img))
+    fx['pass_tape'], fx['bounce_tape'] = pass_tape, bounce_tape
+    fx['img_after_first_pass'] = images[0]
+    fx['img'] = images[-1]
+    fx['n_segments'] = np.array(len(snapshots))
+    for b, snap in enumerate(snapshots):
+        for key, value in snap.items():
+            fx['seg%d_%s' % (b, key)] = np.asarray(value)
+    fx['program_kernels'] = np.array(sorted(acc.kernels))
+    return fx
+
+
+def main():
+    names = sys.argv[1:] or ['scene-dev', 'scene-three-objects', 'scene-test']
+    os.makedirs(OUT, exist_ok=True)
+    for name in names:
+        size = (64, 48) if name != 'scene-test' else (64, 48)
+        fx = make_fixture(name, size, n_passes=3, seed=11)
+        path = os.path.join(OUT, name + '.npz')
+        np.savez_compressed(path, **fx)
+        print(name, '->', path, '%.1f kB' % (os.path.getsize(path) / 1e3),
+              'segments recorded:', int(fx['n_segments']))
+
+
+if __name__ == '__main__':
+    main()
