@@ -1021,3 +1021,8 @@ int orc_first_hit(const orc_scene *sc, const float *cam, const float *pass_tape,
     }
     return 0;
 }
+
+/* the shared exp / log / tan, exported so that tests can measure their accuracy */
+float orc_math_exp(float x) { return clr_expf(x); }
+float orc_math_log(float x) { return clr_logf(x); }
+float orc_math_tan(float x) { return clr_tanf(x); }

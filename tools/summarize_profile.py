@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof/* (tools/profile.sh) into profiles/<tag>_* files.
+
+Writes the kernel stats CSV as is, a per-launch counter table for clr_render, and
+profiles/pmc_traffic.json with the HBM bytes per launch that bench.py reports as
+roofline.traffic.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte
+requests as 64 bytes for wide coalesced reads, so it is doubled
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM section).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'gpurun_out', 'prof')
+DST = os.path.join(ROOT, 'profiles')
+
+
+def main(tag):
+    os.makedirs(DST, exist_ok=True)
+    stats = glob.glob(os.path.join(SRC, 'trace', '*', '*_kernel_stats.csv'))[0]
+    shutil.copy(stats, os.path.join(DST, tag + '_kernel_stats.csv'))
+    trace = glob.glob(os.path.join(SRC, 'trace', '*', '*_kernel_trace.csv'))[0]
+    rows = [r for r in csv.DictReader(open(trace)) if r['Kernel_Name'] == 'clr_render']
+    durations = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
+    counters = collections.OrderedDict()
+    for d in ('pmc_sq', 'pmc_fetch', 'pmc_write', 'pmc_grbm'):
+        for f in glob.glob(os.path.join(SRC, d, '*', '*_counter_collection.csv')):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if r['Kernel_Name'] == 'clr_render':
+                    agg[r['Counter_Name']].append(float(r['Counter_Value']))
+            for k, v in sorted(agg.items()):
+                counters[k] = sum(v) / len(v)
+    fetch = counters.get('FETCH_SIZE', 0.0) * 1024 * 2      # gfx950 correction, see docstring
+    write = counters.get('WRITE_SIZE', 0.0) * 1024
+    summary = {
+        'kernel': 'clr_render', 'launches': len(rows),
+        'avg_ms': sum(durations) / len(durations), 'min_ms': min(durations), 'max_ms': max(durations),
+        'vgpr': int(rows[0]['VGPR_Count']), 'sgpr': int(rows[0]['SGPR_Count']),
+        'grid': int(rows[0]['Grid_Size_X']), 'workgroup': int(rows[0]['Workgroup_Size_X']),
+        'counters_per_launch': counters,
+        'hbm_read_bytes_per_launch': fetch, 'hbm_write_bytes_per_launch': write,
+        'hbm_bytes_per_launch': fetch + write,
+    }
+    c = counters
+    if 'SQ_INSTS_VALU' in c and 'SQ_WAVES' in c:
+        summary['valu_insts_per_wave'] = c['SQ_INSTS_VALU'] / c['SQ_WAVES']
+        summary['salu_insts_per_wave'] = c['SQ_INSTS_SALU'] / c['SQ_WAVES']
+        # one wave64 VALU instruction occupies a SIMD-32 for 2 cycles; 256 CUs x 4 SIMDs
+        if 'GRBM_GUI_ACTIVE' in c:
+            cycles = c['GRBM_GUI_ACTIVE'] / 8.0          # summed over the 8 XCDs
+            summary['shader_clock_ghz'] = cycles / (summary['avg_ms'] * 1e6)
+            summary['valu_issue_utilisation'] = c['SQ_INSTS_VALU'] * 2.0 / (cycles * 1024)
+        if 'SQ_THREAD_CYCLES_VALU' in c and 'SQ_ACTIVE_INST_VALU' in c:
+            summary['valu_lane_utilisation'] = c['SQ_THREAD_CYCLES_VALU'] / (c['SQ_ACTIVE_INST_VALU'] * 64.0) \
+                if c['SQ_ACTIVE_INST_VALU'] else None
+    json.dump(summary, open(os.path.join(DST, tag + '_clr_render.json'), 'w'), indent=1)
+    json.dump({'hbm_bytes_per_launch': fetch + write, 'source': tag + '_clr_render.json'},
+              open(os.path.join(DST, 'pmc_traffic.json'), 'w'))
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1] if len(sys.argv) > 1 else 'r01')
