@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument('--size', default='1920x1080')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--regenerate', type=int, default=0)
+    ap.add_argument('--build-options', default=None,
+                    help='hiprtc options instead of the parity set (-O3 -ffp-contract=off)')
+    ap.add_argument('--bake', type=int, default=None, help='1/0: bake scene parameters into the program')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
@@ -94,7 +97,9 @@ def main():
     scene.image.size = (width, height)
     scene.samples_per_pixel = (args.steps + args.warmup) * args.passes_per_step * world
 
-    r = Renderer(scene, seed=args.seed, device_index=local_rank)
+    r = Renderer(scene, seed=args.seed, device_index=local_rank,
+                 build_options=args.build_options.split() if args.build_options else None,
+                 bake_parameters=None if args.bake is None else bool(args.bake))
     r.regenerate = bool(args.regenerate)
     img = torch.zeros((r.n_pixels, 4), dtype=torch.float32, device='cuda')
     r.use_image_buffer(img.data_ptr())

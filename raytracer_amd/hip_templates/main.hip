@@ -5,7 +5,17 @@
 {% include 'static.hip' %}
 
 // ---- scene tables, filled by the host after the module is loaded
-__constant__ float4 clr_params[{{ [renderer.n_param_slots, 1]|max }}];     // per object: declared parameters, then 4 rows of the inverse affine
+// clr_params, per object: declared parameters, then 4 rows of the inverse affine
+### if renderer.bake_parameters
+// baked into the program: with the object loops unrolled every parameter becomes an immediate
+__constant__ const float4 clr_params[{{ [renderer.n_param_slots, 1]|max }}] = {
+### for row in renderer.param_table_literals()
+    { {{ row|join(', ') }} },
+### endfor
+};
+### else
+__constant__ float4 clr_params[{{ [renderer.n_param_slots, 1]|max }}];
+### endif
 __constant__ int clr_data_offsets[{{ [2*n_objects, 2]|max }}];              // per object: offset into vector_data, integer_data
 ### if shader.rgb
 __constant__ float4 clr_material_colors[{{ 5*(n_objects+1) }}];
@@ -41,7 +51,7 @@ CLR_FN void clr_closest_hit(const vec3 pos, const vec3 ray, float &isec_dist, ui
     const uint inside, const float4 * __restrict__ vector_data, const int * __restrict__ integer_data)
 {
 ### for tracer, count, offset in renderer.object_groups
-    #pragma unroll {{ [count, 8]|min }}
+    #pragma unroll {{ count if renderer.bake_parameters else [count, 8]|min }}
     for (int i = 0; i < {{ count }}; ++i)
         {{ tracer.tracer_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject,
             last_whichobject, last_which_subobject, inside, vector_data, integer_data,
@@ -76,7 +86,7 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
     ray = ray / isec_dist;
     float shadow_mask = 1.0f;
 ### for tracer, count, offset in renderer.object_groups
-    #pragma unroll {{ [count, 8]|min }}
+    #pragma unroll {{ count if renderer.bake_parameters else [count, 8]|min }}
     for (int i = 0; i < {{ count }}; ++i)
         if ({{ offset+1 }} + i != light_id)
             {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,

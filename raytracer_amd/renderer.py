@@ -25,7 +25,7 @@ DEBUG_RECORD = 6     # float4 per (segment, pixel) in the debug dump
 class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
-                 device_index=0):
+                 device_index=0, bake_parameters=None):
         self.scene = scene
         self.shader = scene.shader(scene)
         self.rng = np.random.RandomState(seed)
@@ -37,6 +37,8 @@ class Renderer:
         self._init_camera_and_image()
         self._init_materials()
 
+        # small scenes: bake the per-object parameters into the program text as literals
+        self.bake_parameters = len(scene.objects) <= 48 if bake_parameters is None else bake_parameters
         self.program_code = Compiler(self).make_program()
         self.build_options = list(build_options if build_options is not None else PARITY_OPTIONS)
         extra = getattr(args, 'cl_build_options', None)
@@ -128,6 +130,10 @@ class Renderer:
             assert len(strides) == 1, "objects of one group must share a parameter layout"
             self.group_param_base.append(self.object_param_base[offset])
             self.group_param_stride.append(strides.pop())
+
+    def param_table_literals(self):
+        """The parameter table as exact C++17 hexadecimal float literals, row by row."""
+        return [[float(v).hex() + 'f' for v in row] for row in self.param_table]
 
     def _init_misc(self):
         # consumes the RNG exactly like the reference (renderer.py:84-85)
@@ -251,7 +257,7 @@ class Renderer:
         self.dev_vector_data = acc.to_device(self.vector_data)
         self.dev_integer_data = acc.to_device(self.integer_data)
         self.prog = acc.build_program(self.program_code, self.build_options)
-        if self.n_param_slots:
+        if self.n_param_slots and not self.bake_parameters:
             acc.set_global('clr_params', self.param_table)
         acc.set_global('clr_data_offsets', self.data_offsets)
         if self.shader.rgb:
