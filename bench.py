@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument('--build-options', default=None,
                     help='hiprtc options instead of the parity set (-O3 -ffp-contract=off)')
     ap.add_argument('--bake', type=int, default=None, help='1/0: bake scene parameters into the program')
+    ap.add_argument('--partition', choices=['passes', 'tiles'], default='passes',
+                    help='passes: pass j on rank j mod N (weak scaling); tiles: every rank renders '
+                         'all passes of its own slice of the frame (strong scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
@@ -97,17 +100,26 @@ def main():
     scene.image.size = (width, height)
     scene.samples_per_pixel = (args.steps + args.warmup) * args.passes_per_step * world
 
-    r = Renderer(scene, seed=args.seed, device_index=local_rank,
+    ray_range = None
+    if args.partition == 'tiles' and world > 1:
+        per_rank = -(-(width * height) // world // 256) * 256      # whole blocks of 256 rays
+        first = min(rank * per_rank, width * height)
+        ray_range = (first, max(min(per_rank, width * height - first), 256))
+    r = Renderer(scene, seed=args.seed, device_index=local_rank, ray_range=ray_range,
                  build_options=args.build_options.split() if args.build_options else None,
                  bake_parameters=None if args.bake is None else bool(args.bake))
     r.regenerate = bool(args.regenerate)
-    img = torch.zeros((r.n_pixels, 4), dtype=torch.float32, device='cuda')
+    tiles = ray_range is not None
+    frame = torch.zeros((width * height, 4), dtype=torch.float32, device='cuda')
+    img = frame[ray_range[0]:ray_range[0] + ray_range[1]] if tiles else frame
     r.use_image_buffer(img.data_ptr())
 
     # one global tape (same seed on every rank); rank g renders passes g, g+N, g+2N, ...
     P = args.passes_per_step
-    total = (args.steps + args.warmup) * P * world
-    tape = stripe(r.make_tape(0, total), rank, world)
+    total = (args.steps + args.warmup) * P * (1 if tiles else world)
+    tape = r.make_tape(0, total)
+    if not tiles:
+        tape = stripe(tape, rank, world)
     r.upload_tape(tape)
 
     def sync():
@@ -118,16 +130,16 @@ def main():
     for w in range(args.warmup):
         r.render_resident(w * P, P)
     if world > 1:
-        warm = img.clone()
+        warm = frame.clone()
         dist.all_reduce(warm)          # set up the communicator outside the timed region
-    img.zero_()
+    frame.zero_()
     sync()
     t0 = time.perf_counter()
     kernel_ms = []
     for k in range(args.steps):
         kernel_ms.append(r.render_resident((args.warmup + k) * P, P))
     if world > 1:
-        dist.all_reduce(img)
+        dist.all_reduce(frame)         # sum of private accumulators / gather of disjoint tiles
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -135,22 +147,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    samples = float(r.n_pixels) * P * args.steps * world
+    samples = float(width * height) * P * args.steps * (1 if tiles else world)
     result = {
-        'metric': 'Msamples/sec (px*spp/s) on scene-dev', 'value': samples / elapsed / 1e6,
+        'metric': 'Msamples/sec (px*spp/s) on %s' % args.scene, 'value': samples / elapsed / 1e6,
         'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'strong' if tiles else 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s %dx%d, %d sample passes per step (RGB, next-event light, '
                                'max_bounces %d), broadcast random tape, parity build '
                                '(-ffp-contract=off)' % (args.scene, width, height, P, scene.max_bounces),
                    'passes_per_step': P, 'pixels': r.n_pixels,
-                   'parallelism': 'pass-striped x%d, one all-reduce' % world if world > 1 else 'single GPU'},
+                   'parallelism': ('%s x%d, one all-reduce' % ('tile-partitioned' if tiles else 'pass-striped', world))
+                                  if world > 1 else 'single GPU'},
     }
     if rank == 0:
-        final = img.cpu().numpy()
+        final = frame.cpu().numpy()
         assert np.isfinite(final).all() and final[:, :3].mean() > 0, "bad image"
-        result['image_mean'] = float(final[:, :3].mean() / (P * args.steps * world))
+        result['image_mean'] = float(final[:, :3].mean() / (P * args.steps * (1 if tiles else world)))
         flops_per_sample = None
         if world == 1 and not args.no_cpu_baseline:
             base, flops_per_sample = cpu_baseline(r, tape, args.cpu_seconds)

@@ -25,8 +25,11 @@ DEBUG_RECORD = 6     # float4 per (segment, pixel) in the debug dump
 class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
-                 device_index=0, bake_parameters=None):
+                 device_index=0, bake_parameters=None, ray_range=None):
         self.scene = scene
+        # tile partitioning: (first ray, count) in ray order; a contiguous range of ray
+        # indices is a set of 4-pixel-wide column blocks of the frame (get_image_order)
+        self.ray_range = ray_range
         self.shader = scene.shader(scene)
         self.rng = np.random.RandomState(seed)
 
@@ -149,6 +152,11 @@ class Renderer:
         self.img_shape = tuple(scene.image.size[::-1])          # (H, W)
         self.n_pixels = self.img_shape[0] * self.img_shape[1]
         self.image_order = self.get_image_order()
+        if self.ray_range is not None:
+            first, count = self.ray_range
+            assert 0 <= first and first + count <= self.n_pixels and count > 0
+            self.image_order = self.image_order[first:first + count]
+            self.n_pixels = count
         self.host_cam = Accelerator.host_vec3_array(
             cam[self.image_order[:, 0], self.image_order[:, 1], 0:3])
 
@@ -354,7 +362,7 @@ class Renderer:
     # ------------------------------------------------------------------ results
     def unpermute(self, per_ray):
         """(n_pixels, C) in ray order -> (H, W, C) image."""
-        out = np.empty(self.img_shape + per_ray.shape[1:], dtype=per_ray.dtype)
+        out = np.zeros(self.img_shape + per_ray.shape[1:], dtype=per_ray.dtype)
         out[self.image_order[:, 0], self.image_order[:, 1]] = per_ray
         return out
 

@@ -18,7 +18,12 @@ def pytest_configure(config):
 
 def load_scene(name, size=None, **overrides):
     """A fresh copy of a shipped scene ('scene-dev', 'scene-three-objects', 'scene-test')."""
-    scene = runpy.run_path(os.path.join(SCENE_DIR, name + '.py'))['scene']
+    if name == 'scene-dev-spectral':
+        scene = runpy.run_path(os.path.join(SCENE_DIR, 'scene-dev.py'))['make_scene'](spectral=True)
+    elif name == 'scene-stairs-small':     # 12 of the 65 steps: same classes, quicker to compile
+        scene = runpy.run_path(os.path.join(SCENE_DIR, 'scene-stairs.py'))['make_scene'](12)
+    else:
+        scene = runpy.run_path(os.path.join(SCENE_DIR, name + '.py'))['scene']
     if size is not None:
         scene.image.size = tuple(size)
     for key, value in overrides.items():

@@ -8,7 +8,8 @@ from raytracer_amd import objects as shapes
 from conftest import load_scene
 
 
-@pytest.mark.parametrize('name', ['scene-dev', 'scene-three-objects', 'scene-test'])
+@pytest.mark.parametrize('name', ['scene-dev', 'scene-three-objects', 'scene-test', 'scene-dev-spectral',
+                                  'scene-stairs-small'])
 def test_scene_program_compiles_for_gfx950(name):
     r = Renderer(load_scene(name, (64, 48)), device=False, seed=0)
     code = r.program_code

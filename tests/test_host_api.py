@@ -197,3 +197,14 @@ def test_camera_helpers():
     assert np.allclose(np.linalg.norm(rays, axis=-1), 1.0)
     q = camera.quasi_random_direction_sample(10)
     assert q.shape == (10, 3) and np.all(q[:, 2] > 0)
+
+
+def test_ray_range_selects_column_blocks():
+    whole = Renderer(load_scene('scene-dev', (16, 16)), device=False, seed=0)
+    part = Renderer(load_scene('scene-dev', (16, 16)), device=False, seed=0, ray_range=(64, 128))
+    assert part.n_pixels == 128
+    assert np.array_equal(part.host_cam, whole.host_cam[64:192])
+    cols = np.unique(part.image_order[:, 1])
+    assert list(cols) == list(range(4, 12))          # two 4-pixel-wide column blocks of 16 rows
+    img = part.unpermute(np.ones((128, 3), np.float32))
+    assert img.shape == (16, 16, 3) and img[:, 4:12].all() and not img[:, :4].any() and not img[:, 12:].any()

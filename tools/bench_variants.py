@@ -1,0 +1,48 @@
+"""A/B timing of build-option variants of the render kernel in ONE process, interleaved
+rounds (cdna_hip_programming.md §5.4 rule 24).  Development tool."""
+import runpy, sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracer_amd.renderer import Renderer
+
+VARIANTS = {
+    'parity': ['-O3', '-ffp-contract=off'],
+    'contract': ['-O3', '-ffp-contract=fast'],
+    'fastdiv': ['-O3', '-ffp-contract=fast', '-fno-hip-fp32-correctly-rounded-divide-sqrt'],
+    'fastmath': ['-O3', '-ffast-math', '-fno-hip-fp32-correctly-rounded-divide-sqrt'],
+}
+
+def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
+    rs = {}
+    tape = None
+    for name, opts in VARIANTS.items():
+        scene = runpy.run_path('raytracer_amd/scenes/%s.py' % scene_name)['scene']
+        scene.image.size = size
+        r = Renderer(scene, seed=0, build_options=opts)
+        if tape is None:
+            tape = r.make_tape(0, passes)
+        r.upload_tape(tape)
+        r.render_resident(0, passes)
+        rs[name] = r
+    ref = None
+    times = {k: [] for k in rs}
+    for _ in range(rounds):
+        for name, r in rs.items():
+            times[name].append(r.render_resident(0, passes))
+    for name, r in rs.items():
+        r.img.fill(0)
+        r.render_resident(0, passes)
+        img = r.img.get()[:, :3].astype(np.float64)
+        if ref is None:
+            ref = img
+        ids, t, _ = r.first_hit(tape)
+        if name == 'parity':
+            ids0, t0 = ids, t
+        rmse = np.sqrt(np.mean((img - ref) ** 2)) / np.sqrt(np.mean(ref ** 2))
+        ms = np.median(times[name])
+        print('%-9s median %.3f ms min %.3f  %.0f Msamples/s  rel-RMSE vs parity %.2e  first-hit id flips %d  max t rel err %.2e'
+              % (name, ms, min(times[name]), r.n_pixels * passes / ms / 1e3, rmse, int((ids != ids0).any(axis=1).sum()),
+                 float(np.max(np.abs(t - t0) / np.abs(t0)))))
+
+if __name__ == '__main__':
+    main(*(sys.argv[1:2] or ['scene-dev']))
