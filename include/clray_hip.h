@@ -96,6 +96,27 @@ int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape,
                   const void *vector_data, const void *integer_data, int n_pixels,
                   void *out_ids, void *out_t, void *out_normal, void *stream);
 
+/* ---- host-side octree builder: replaces Octree.build + get_data (objects/octree.py:69-156)
+ * for meshes the reference's dense numpy construction cannot handle.  No device needed.
+ * vertices: n_vertices x 3 floats, faces: n_faces x 3 ints. */
+typedef struct clr_octree clr_octree;
+typedef struct clr_octree_info_t {
+    int n_nodes, n_leaves, max_depth;
+    int stream_length;        /* ints in the reference-format node stream */
+    int root_data_offset;     /* position of the root header in that stream */
+    int flat_triangles;       /* (leaf, face) records in the flattened layout */
+    double root_origin[3];
+    double root_size;
+} clr_octree_info_t;
+
+int clr_octree_build(const float *vertices, int n_vertices, const int *faces, int n_faces,
+                     int max_depth, int max_faces_per_leaf, clr_octree **out);
+int clr_octree_info(const clr_octree *oct, clr_octree_info_t *info);
+/* Copies out whichever destinations are not NULL: the reference stream (stream_length ints),
+ * the flattened nodes (2 ints per node) and triangle records (12 floats per record). */
+int clr_octree_copy(const clr_octree *oct, int *stream, int *flat_nodes, float *flat_tris);
+int clr_octree_destroy(clr_octree *oct);
+
 #ifdef __cplusplus
 }
 #endif

@@ -339,8 +339,7 @@ static vec3 trimesh_normal(const orc_scene *sc, const orc_object *o, vec3 pos, u
 }
 
 /* objects/Octree.cl:32-164 */
-#define ORC_MAX_OCTREE_DEPTH 8
-#define ORC_MAX_TOTAL_ITR 300
+#define ORC_OCTREE_STACK 24   /* capacity; the reference uses MAX_DEPTH + 1 = 8 levels and 300 steps */
 static void octree_tracer(const orc_scene *sc, const orc_object *o, vec3 origin, vec3 ray,
                           float old_isec_dist, float *p_new, uint *p_subobject, int origin_self) {
     const float *vd = sc->vector_data + 4 * o->vec_offset;
@@ -366,17 +365,18 @@ static void octree_tracer(const orc_scene *sc, const orc_object *o, vec3 origin,
     const int *octree_data = idata + face_data_length;
     int ocx = 0, ocy = 0, ocz = 0;          /* integer coordinates of the current node */
     int lcx = 0, lcy = 0, lcz = 0;          /* last bit of each */
-    int path[ORC_MAX_OCTREE_DEPTH];
+    int path[ORC_OCTREE_STACK];
+    const int levels = o->ip[4] > 0 ? o->ip[4] : 8, max_steps = o->ip[5] > 0 ? o->ip[5] : 300;
     path[0] = root_data_offset;
     uint depth = 0;
     uint old_subobject = *p_subobject, subobject = 0;
     float node_size = root_size;
 
-    for (int itr = 0; itr < ORC_MAX_TOTAL_ITR; itr++) {
+    for (int itr = 0; itr < max_steps; itr++) {
         vec3 ray_pos = add3(origin, lscale3(isec_begin, ray)), node_origin = v3(0, 0, 0);
         int child_mask = 0, data_ptr = 0, child_idx;
 
-        while (depth < ORC_MAX_OCTREE_DEPTH - 1) {       /* descend to the leaf holding ray_pos */
+        while ((int)depth < levels - 1) {       /* descend to the leaf holding ray_pos */
             child_mask = octree_data[path[depth]];
             data_ptr = octree_data[path[depth] + 1];
             node_origin = add3(root_origin, scale3(v3((float)ocx, (float)ocy, (float)ocz), node_size));

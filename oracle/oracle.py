@@ -186,8 +186,9 @@ class OracleScene:
             o.vec_offset, o.int_offset = n_vec, n_int
             if tracer.has_data():
                 data = tracer.get_data()
-                vec = np.zeros((np.asarray(data['vector']).shape[0], 4), dtype=np.float32)
-                vec[:, :3] = data['vector']
+                raw = np.asarray(data['vector'], dtype=np.float32)
+                vec = np.zeros((raw.shape[0], 4), dtype=np.float32)
+                vec[:, :raw.shape[1]] = raw
                 vectors.append(vec)
                 n_vec += vec.shape[0]
                 ints = np.ravel(data['integer']).astype(np.int32)
@@ -241,6 +242,10 @@ class OracleScene:
                 components.append(rec)
         elif isinstance(tracer, shapes.Octree):
             o.kind = ORC_OCTREE
+            if tracer.layout != 'stream':
+                raise NotImplementedError("the oracle follows the reference's octree stream; build the "
+                                          "same tree with layout='stream' for it")
+            o.ip[4], o.ip[5] = tracer.levels, tracer.max_steps
             values = tracer.parameter_values()
             o.ip[0], o.ip[1], o.ip[2], o.ip[3] = [int(v) for v in values[:4]]
             o.fp[0:3] = [float(x) for x in np.float32(values[4])]

@@ -36,6 +36,13 @@ class RenderArgs(ctypes.Structure):
                 ('debug_dump', ctypes.c_void_p)]
 
 
+class OctreeInfo(ctypes.Structure):
+    _fields_ = [('n_nodes', ctypes.c_int), ('n_leaves', ctypes.c_int), ('max_depth', ctypes.c_int),
+                ('stream_length', ctypes.c_int), ('root_data_offset', ctypes.c_int),
+                ('flat_triangles', ctypes.c_int), ('root_origin', ctypes.c_double * 3),
+                ('root_size', ctypes.c_double)]
+
+
 _lib = None
 
 
@@ -69,6 +76,10 @@ def load_library():
                             P(ctypes.c_float)]),
         'clr_render_passes': (ci, [vp, P(RenderArgs), vp, P(ctypes.c_float)]),
         'clr_first_hit': (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+        'clr_octree_build': (ci, [vp, ci, vp, ci, ci, ci, P(vp)]),
+        'clr_octree_info': (ci, [vp, P(OctreeInfo)]),
+        'clr_octree_copy': (ci, [vp, vp, vp, vp]),
+        'clr_octree_destroy': (ci, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -96,6 +107,34 @@ def compile_only(source, options=(), arch='gfx950'):
     size = ctypes.c_size_t(0)
     _check(lib.clr_compile_only(source.encode('ascii'), n, arr, arch.encode(), ctypes.byref(size)))
     return size.value
+
+
+def build_octree(vertices, faces, max_depth, max_faces_per_leaf):
+    """Native (C++) octree construction; host only.  Returns a dict with the reference-format
+    node stream, the flattened nodes / triangle records and the root cube."""
+    lib = load_library()
+    vertices = np.ascontiguousarray(vertices, dtype=np.float32)
+    faces = np.ascontiguousarray(faces, dtype=np.int32)
+    handle = ctypes.c_void_p()
+    rc = lib.clr_octree_build(vertices.ctypes.data_as(ctypes.c_void_p), vertices.shape[0],
+                              faces.ctypes.data_as(ctypes.c_void_p), faces.shape[0],
+                              int(max_depth), int(max_faces_per_leaf), ctypes.byref(handle))
+    if rc != 0:
+        raise ClrError("clr_octree_build: bad mesh or parameters (face index out of range, "
+                       "max_depth outside 0..20)")
+    try:
+        info = OctreeInfo()
+        lib.clr_octree_info(handle, ctypes.byref(info))
+        stream = np.empty(info.stream_length, dtype=np.int32)
+        nodes = np.empty((info.n_nodes, 2), dtype=np.int32)
+        tris = np.empty((info.flat_triangles * 3, 4), dtype=np.float32)
+        lib.clr_octree_copy(handle, stream.ctypes.data_as(ctypes.c_void_p),
+                            nodes.ctypes.data_as(ctypes.c_void_p), tris.ctypes.data_as(ctypes.c_void_p))
+    finally:
+        lib.clr_octree_destroy(handle)
+    return {'stream': stream, 'root_data_offset': info.root_data_offset, 'flat_nodes': nodes,
+            'flat_tris': tris, 'root_origin': np.array(info.root_origin[:]), 'root_size': info.root_size,
+            'n_nodes': info.n_nodes, 'n_leaves': info.n_leaves, 'max_depth': info.max_depth}
 
 
 class DeviceArray:

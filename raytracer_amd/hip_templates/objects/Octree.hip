@@ -1,13 +1,45 @@
 ### extends 'tracer.hip'
 ### import 'objects/TriangleMesh.hip' as tri_mesh
-{#- octree traversal in the reference's serialised integer stream
-    (reference objects/Octree.cl:32-168): clip the ray to the root cube, locate the leaf under
-    the entry point, test its triangles up to the leaf's exit distance, hop to the neighbour
-    cell through integer cell coordinates, climbing while the hop leaves the parent.
-    NOTE: this is the parity layout; the flattened HBM layout for large meshes is separate. -#}
+{#- octree traversal (reference objects/Octree.cl:32-168): clip the ray to the root cube,
+    locate the leaf under the entry point, test its triangles up to the leaf's exit distance,
+    hop to the neighbour cell through integer cell coordinates, climbing while the hop leaves
+    the parent.  Two data layouts, same visiting order and same arithmetic (bit-identical hits):
+      stream: the reference's integer stream (header = [child mask, payload offset]);
+      flat  : int2 node records with the 8 children of a node contiguous, and per-leaf
+              pre-gathered triangle records (v0|face id, e1, e2 = 48 B, one coalesced run per
+              leaf) instead of face index -> 3 vertex indices -> 3 gathered vertices (60 B).
+    The per-lane stack of node positions lives in LDS (one column per lane: conflict-free),
+    not in scratch memory as a dynamically indexed private array would. -#}
+
+### macro flat_triangle_loop()
+    for (int j = 0; j < n_leaf_triangles; ++j) {
+        const float4 * __restrict__ rec = tris + 3*(first_triangle + j);
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const int face_index = __float_as_int(r0.w);
+        if (prev_face == (uint)face_index && on_surface) continue;
+        const vec3 va = make_vec3(r0);
+        const vec3 e1 = make_vec3(r1);
+        const vec3 e2 = make_vec3(r2);
+        const vec3 pvec = cross(ray, e2);
+        const float det = dot(e1, pvec);
+        const float inv_det = 1.f / det;
+        const vec3 tvec = origin - va;
+        const float u = dot(tvec, pvec) * inv_det;
+        if (u < 0.f || u > 1.f) continue;
+        const vec3 qvec = cross(tvec, e1);
+        const float v = dot(ray, qvec) * inv_det;
+        if (v < 0.f || u + v > 1.f) continue;
+        const float t = dot(e2, qvec) * inv_det;
+        if (t > 0.0f && t < best_t) {
+            best_t = t;
+            face = face_index;
+        }
+    }
+### endmacro
 
 ### macro tracer_function(obj)
     ### call tracer_function_base(obj)
+        ### set flat = obj.layout == 'flat'
         const vec3 slopes = make_vec3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
         const int nx = slopes.x < 0.0f, ny = slopes.y < 0.0f, nz = slopes.z < 0.0f;   // entry walls
         const vec3 far_walls = make_vec3((float)(1 - nx), (float)(1 - ny), (float)(1 - nz));
@@ -21,31 +53,49 @@
         if (seg_begin > seg_end || seg_end < 0.0f || seg_begin > t_limit) return;
 
         const int * __restrict__ octree_data = integer_data + face_data_length;
-        #define CLR_OCTREE_LEVELS {{ obj.__class__.MAX_DEPTH + 1 }}
-        #define CLR_OCTREE_MAX_STEPS 300
+        ### if flat
+        const float4 * __restrict__ tris = vector_data + flat_tri_offset;
+        ### endif
+        const int LEVELS = {{ obj.levels }};
+        const int MAX_STEPS = {{ obj.max_steps }};
+
+        // stack[level] = position of the node on the current branch (stream: header offset,
+        // flat: node index); one LDS column per lane of the 256-thread block
+        __shared__ int stack_lds[{{ obj.levels }} * 256];
+        int *stack = stack_lds + threadIdx.x;
+        #define STACK(level) stack[(level) * 256]
 
         int cx = 0, cy = 0, cz = 0;       // integer cell coordinates at the current depth
         int bx = 0, by = 0, bz = 0;       // their lowest bits (position inside the parent)
-        int path[CLR_OCTREE_LEVELS];
-        path[0] = root_data_offset;
-        uint depth = 0;
+        STACK(0) = root_data_offset;
+        int depth = 0;
         uint prev_face = *p_subobject, face = 0;
         float node_size = root_size;
 
-        for (int step = 0; step < CLR_OCTREE_MAX_STEPS; step++) {
+        for (int step = 0; step < MAX_STEPS; step++) {
             vec3 ray_pos = origin + seg_begin * ray, node_origin = make_vec3(0.0f, 0.0f, 0.0f);
-            int child_mask = 0, data_ptr = 0, child_idx;
+            int head = 0, payload = 0, child_idx;
 
-            while (depth < CLR_OCTREE_LEVELS-1) {
-                child_mask = octree_data[path[depth]];
-                data_ptr = octree_data[path[depth]+1];
+            while (depth < LEVELS-1) {
+                const int at = STACK(depth);
+                ### if flat
+                head = octree_data[2*at];          // >= 0: leaf with that many triangles, -1: inner
+                payload = octree_data[2*at+1];     // first triangle record / first child
+                ### else
+                head = octree_data[at];            // child mask; 0 = leaf, 0x100 = empty leaf
+                payload = octree_data[at+1];
+                ### endif
                 node_origin = root_origin + make_vec3((float)cx, (float)cy, (float)cz)*node_size;
-                if (child_mask == 0 || child_mask == 0x100) break;     // leaf / empty leaf
+                ### if flat
+                if (head >= 0) break;
+                ### else
+                if (head == 0 || head == 0x100) break;
+                ### endif
                 const vec3 rc = ray_pos - node_origin;
                 const float half = 0.5f*node_size;
                 bx = 1 - (rc.x < half); by = 1 - (rc.y < half); bz = 1 - (rc.z < half);
                 child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
-                path[depth+1] = data_ptr + child_idx*2;
+                STACK(depth+1) = payload + child_idx{{ '' if flat else '*2' }};
                 cx = (cx << 1) | bx; cy = (cy << 1) | by; cz = (cz << 1) | bz;
                 node_size *= 0.5f;
                 depth++;
@@ -54,12 +104,24 @@
             t_out = slopes * (node_origin - origin + far_walls*node_size);
             seg_end = fminf(fminf(t_out.x, t_out.y), t_out.z);
 
-            if (child_mask != 0x100) {
-                const uint n_triangles = (uint)max(octree_data[data_ptr], 0);
+            ### if flat
+            if (head > 0) {
+                const int n_leaf_triangles = head, first_triangle = payload;
+                float best_t = seg_end;
+                {{ flat_triangle_loop() }}
+                if (best_t < seg_end) {
+                    *t_hit = best_t;
+                    *p_subobject = face;
+                    return;
+                }
+            }
+            ### else
+            if (head != 0x100) {
+                const uint n_triangles = (uint)max(octree_data[payload], 0);
                 if (n_triangles > 0) {
                     float best_t = seg_end;
                     ### call(j) tri_mesh.triangle_loop()
-                        octree_data[data_ptr + 1 + {{ j }}]
+                        octree_data[payload + 1 + {{ j }}]
                     ### endcall
                     if (best_t < seg_end) {
                         *t_hit = best_t;
@@ -68,6 +130,7 @@
                     }
                 }
             }
+            ### endif
 
             int hx = 0, hy = 0, hz = 0;
             if (seg_end == t_out.x) hx = sx;
@@ -86,14 +149,16 @@
 
             cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
             child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
-            data_ptr = octree_data[path[depth-1]+1];
-            path[depth] = data_ptr + child_idx*2;
+            ### if flat
+            STACK(depth) = octree_data[2*STACK(depth-1)+1] + child_idx;
+            ### else
+            STACK(depth) = octree_data[STACK(depth-1)+1] + child_idx*2;
+            ### endif
 
             seg_begin = seg_end;
             if (seg_begin > t_limit) return;
         }
-        #undef CLR_OCTREE_LEVELS
-        #undef CLR_OCTREE_MAX_STEPS
+        #undef STACK
     ### endcall
 ### endmacro
 

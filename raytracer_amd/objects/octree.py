@@ -18,16 +18,32 @@ class Octree(Tracer):
 
     MAX_DEPTH = 7
 
-    def __init__(self, triangle_mesh, max_depth=3, max_faces_per_leaf=5):
+    def __init__(self, triangle_mesh, max_depth=3, max_faces_per_leaf=5, builder='python',
+                 layout='stream', max_steps=300):
+        """builder: 'python' (restatement of the reference's construction) or 'native' (C++
+        builder of libclray_hip.so, same tree, any size, max_depth up to 20).
+        layout: 'stream' = the reference's integer stream; 'flat' = flattened nodes + per-leaf
+        pre-gathered triangle records (needs the native builder).
+        max_steps: leaf-step budget of the traversal (300 in the reference)."""
+        if layout == 'flat':
+            builder = 'native'
+        self.builder, self.layout, self.max_steps = builder, layout, max_steps
         mesh_pose = triangle_mesh.coordinates
         self.triangle_mesh = triangle_mesh
         Tracer.__init__(self)          # assigns an identity pose through the setter below
         self.coordinates = mesh_pose   # ... so put the mesh's own pose back
         self.max_depth = max_depth
         self.max_faces_per_leaf = max_faces_per_leaf
-        if self.max_depth >= self.__class__.MAX_DEPTH:
+        if self.max_depth >= self.__class__.MAX_DEPTH and builder == 'python':
             raise RuntimeError("max_depth >= MAX_DEPTH")
+        if layout != 'stream' or max_steps != 300 or self.max_depth >= self.__class__.MAX_DEPTH:
+            self.unique_tracer_id = '_%s_d%d_s%d' % (layout, self.levels, max_steps)
         self.build()
+
+    @property
+    def levels(self):
+        """Entries of the traversal stack (reference: MAX_DEPTH + 1)."""
+        return max(self.__class__.MAX_DEPTH + 1, self.max_depth + 2)
 
     @property
     def auto_flip_normal(self):
@@ -81,6 +97,8 @@ class Octree(Tracer):
             return self.children
 
     def build(self):
+        if self.builder == 'native':
+            return self._build_native()
         mesh = self.triangle_mesh
         self.center, self.size = mesh.get_bounding_cube()
         self.center = numpy.asarray(self.center, dtype=numpy.float64)
@@ -118,8 +136,36 @@ class Octree(Tracer):
             active_nodes = next_nodes
             depth += 1
 
+    def _build_native(self):
+        import types
+        from ..accelerator import build_octree
+        mesh = self.triangle_mesh
+        self._native = build_octree(mesh.vertices, mesh.faces, self.max_depth, self.max_faces_per_leaf)
+        self.root = types.SimpleNamespace(origin=self._native['root_origin'], size=self._native['root_size'])
+        self.origin, self.size = self.root.origin, self.root.size
+        self.n_leaves = self._native['n_leaves']
+
+    def _native_data(self):
+        native = self._native
+        data = self.triangle_mesh.get_data()
+        faces = numpy.ravel(data['integer']).astype(numpy.int32)
+        if self.layout == 'flat':
+            vectors = numpy.zeros((numpy.asarray(data['vector']).shape[0], 4), dtype=numpy.float32)
+            vectors[:, :3] = data['vector']
+            self.flat_tri_offset = vectors.shape[0]
+            data['vector'] = numpy.vstack([vectors, native['flat_tris']])
+            data['integer'] = numpy.concatenate([faces, native['flat_nodes'].ravel()])
+            self.root_data_offset = 0
+        else:
+            self.flat_tri_offset = 0
+            self.root_data_offset = int(native['root_data_offset'])
+            data['integer'] = numpy.concatenate([faces, native['stream']])
+        return data
+
     def get_data(self):
         """Serialise: mesh faces (3N ints) followed by the node stream."""
+        if self.builder == 'native':
+            return self._native_data()
         def write_node(node, stream):
             child_mask = 0
             if node.is_leaf():
@@ -156,14 +202,16 @@ class Octree(Tracer):
         return len(self.triangle_mesh.faces)
 
     def parameter_declarations(self):
-        return ['int n_vertices', 'int n_triangles', 'int root_data_offset',
-                'int face_data_length', 'float3 root_origin', 'float root_size']
+        decls = ['int n_vertices', 'int n_triangles', 'int root_data_offset',
+                 'int face_data_length', 'float3 root_origin', 'float root_size']
+        return decls + ['int flat_tri_offset'] if self.layout == 'flat' else decls
 
     def parameter_values(self):
         if not hasattr(self, 'root_data_offset'):
             self.get_data()
-        return [self.triangle_mesh.n_vertices, self.triangle_mesh.n_faces,
-                self.root_data_offset, self.total_faces * 3, self.root.origin, self.root.size]
+        values = [self.triangle_mesh.n_vertices, self.triangle_mesh.n_faces,
+                  self.root_data_offset, self.total_faces * 3, self.root.origin, self.root.size]
+        return values + [self.flat_tri_offset] if self.layout == 'flat' else values
 
 
 def face_bounding_spheres(vertices, faces):

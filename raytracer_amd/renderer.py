@@ -93,9 +93,9 @@ class Renderer:
             if tracer.has_data():
                 data = tracer.get_data()
                 vec = np.asarray(data['vector'], dtype=np.float32)
-                if vec.ndim != 2 or vec.shape[1] != 3:
+                if vec.ndim != 2 or vec.shape[1] not in (3, 4):
                     raise RuntimeError('invalid vector data shape')
-                vectors.append(vec)
+                vectors.append(vec if vec.shape[1] == 4 else Accelerator.host_vec3_array(vec))
                 n_vec += vec.shape[0]
                 ints = np.ravel(data['integer']).astype(np.int32)
                 integers.append(ints)
@@ -123,7 +123,7 @@ class Renderer:
         self.param_table = np.array(slots, dtype=np.float32).reshape(-1, 4)
         self.n_param_slots = self.param_table.shape[0]
         self.data_offsets = np.array(data_offsets, dtype=np.int32)
-        self.vector_data = (Accelerator.host_vec3_array(np.vstack(vectors)) if vectors
+        self.vector_data = (np.vstack(vectors) if vectors
                             else np.zeros((1, 4), dtype=np.float32))
         self.integer_data = (np.concatenate(integers) if integers else np.zeros(1, dtype=np.int32))
 

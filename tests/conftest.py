@@ -22,6 +22,11 @@ def load_scene(name, size=None, **overrides):
         scene = runpy.run_path(os.path.join(SCENE_DIR, 'scene-dev.py'))['make_scene'](spectral=True)
     elif name == 'scene-stairs-small':     # 12 of the 65 steps: same classes, quicker to compile
         scene = runpy.run_path(os.path.join(SCENE_DIR, 'scene-stairs.py'))['make_scene'](12)
+    elif name.startswith('scene-mesh'):      # 'scene-mesh:<n_u>x<n_v>:<layout>'
+        _, grid, layout = (name.split(':') + ['120x60', 'flat'])[:3] if ':' in name else (name, '120x60', 'flat')
+        n_u, n_v = (int(v) for v in grid.split('x'))
+        make = runpy.run_path(os.path.join(SCENE_DIR, 'scene-mesh.py'), run_name='lib')['make_scene']
+        scene = make(n_u, n_v, layout=layout)
     else:
         scene = runpy.run_path(os.path.join(SCENE_DIR, name + '.py'))['scene']
     if size is not None:

@@ -127,6 +127,31 @@ def test_tile_partition_reassembles_the_frame():
     assert np.array_equal(total, full)
 
 
+def test_flattened_octree_matches_reference_stream_and_oracle():
+    """BASELINE config C4 at reduced size (14 400 triangles): the flattened HBM layout with the
+    LDS stack, the reference-stream layout and the oracle (reference stream) agree bit for bit."""
+    from oracle import oracle
+    flat = Renderer(load_scene('scene-mesh:120x60:flat', (96, 64)), seed=4)
+    stream = Renderer(load_scene('scene-mesh:120x60:stream', (96, 64)), seed=4)
+    osc = oracle.OracleScene(stream)
+    tape = flat.make_tape(0, 4)
+    one = tuple(x[:1] if x is not None else None for x in tape)
+    ids_f, t_f, n_f = flat.first_hit(one)
+    ids_s, t_s, n_s = stream.first_hit(one)
+    ids_o, t_o, n_o = osc.first_hit(one)
+    knot = [i + 1 for i, o in enumerate(flat.scene.objects) if o.name == 'knot'][0]
+    assert (ids_o[:, 0] == knot).mean() > 0.05
+    for ids, t, n in ((ids_f, t_f, n_f), (ids_s, t_s, n_s)):
+        assert np.array_equal(ids, ids_o)
+        assert np.array_equal(bits(t), bits(t_o))
+        assert np.array_equal(bits(n), bits(n_o))
+    flat.render_tape(tape)
+    stream.render_tape(tape)
+    oimg, _, _ = osc.render(tape)
+    assert np.array_equal(bits(flat.img.get()), bits(oimg))
+    assert np.array_equal(bits(stream.img.get()), bits(oimg))
+
+
 def test_batching_is_additive_and_order_preserving():
     """Size-independent property at the full 1080p size: rendering 6 passes in one launch
     equals rendering them as 2 + 4, bit for bit (a lane visits its passes in order)."""

@@ -208,3 +208,34 @@ def test_ray_range_selects_column_blocks():
     assert list(cols) == list(range(4, 12))          # two 4-pixel-wide column blocks of 16 rows
     img = part.unpermute(np.ones((128, 3), np.float32))
     assert img.shape == (16, 16, 3) and img[:, 4:12].all() and not img[:, :4].any() and not img[:, 12:].any()
+
+
+@pytest.mark.parametrize('n,depth,leaf', [(400, 4, 5), (3000, 5, 4), (50, 3, 1)])
+def test_native_octree_builder_reproduces_the_reference_stream(n, depth, leaf):
+    """C++ builder (top-down, per-node face lists) vs the restated reference construction:
+    identical integer stream, root cube and leaf count."""
+    from raytracer_amd import accelerator
+    vertices, faces = random_triangle_soup(n, seed=n)
+    py = shapes.Octree(shapes.TriangleMesh(vertices, faces), max_depth=depth, max_faces_per_leaf=leaf)
+    native = accelerator.build_octree(np.float32(vertices), faces, depth, leaf)
+    assert np.array_equal(py.get_data()['integer'][3 * n:], native['stream'])
+    assert py.root_data_offset == native['root_data_offset']
+    assert np.allclose(py.root.origin, native['root_origin'], rtol=0, atol=1e-12)
+    assert len(py.leaves) == native['n_leaves']
+    # flattened layout: every (leaf, face) reference once, edges pre-subtracted in binary32
+    tris = native['flat_tris'].reshape(-1, 3, 4)
+    assert tris.shape[0] == native['flat_nodes'][native['flat_nodes'][:, 0] > 0, 0].sum()
+    face_ids = tris[:, 0, 3].copy().view(np.int32)
+    v32 = np.float32(vertices)
+    assert np.array_equal(tris[:, 0, :3], v32[faces[face_ids, 0]])
+    assert np.array_equal(tris[:, 1, :3], v32[faces[face_ids, 1]] - v32[faces[face_ids, 0]])
+    assert set(face_ids) == set(range(n))
+
+
+def test_native_octree_rejects_bad_input():
+    from raytracer_amd import accelerator
+    vertices, faces = random_triangle_soup(10)
+    with pytest.raises(accelerator.ClrError):
+        accelerator.build_octree(np.float32(vertices), faces + 1000, 3, 2)
+    with pytest.raises(accelerator.ClrError):
+        accelerator.build_octree(np.float32(vertices), faces, 99, 2)
