@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
 PEAK_FP32_VECTOR_TFLOPS = 157.3        # packed v_pk_fma_f32 (= the dense FP32 MFMA peak)
 PEAK_FP32_SCALAR_FMA_TFLOPS = 78.6     # one v_fma_f32 per lane per issue
+PEAK_HBM_GBS = 8000.0                  # HBM3E spec; ~6300 achievable (same guide)
 
 
 def parse_args():
@@ -35,6 +36,7 @@ def parse_args():
     ap.add_argument('--passes-per-step', type=int, default=32)
     ap.add_argument('--scene', default='scene-dev')
     ap.add_argument('--size', default='1920x1080')
+    ap.add_argument('--mesh-grid', default='1000x500', help='scene-mesh: quads along / around the tube')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--regenerate', type=int, default=0)
     ap.add_argument('--build-options', default=None,
@@ -62,6 +64,7 @@ def cpu_baseline(renderer, tape, target_seconds):
     one = tuple(x[:1] if x is not None else None for x in tape)
     _, _, flops = osc.render(one, n_threads=threads, count_flops=True)
     flops_per_sample = flops / renderer.n_pixels
+    mesh_bytes_per_sample = osc.last_mesh_bytes / renderer.n_pixels
     t0 = time.time()
     osc.render(one, n_threads=threads)
     t_one = time.time() - t0
@@ -75,7 +78,7 @@ def cpu_baseline(renderer, tape, target_seconds):
         'kind': 'port',
         'sample': '%d sample passes of the same %dx%d frame, same tape (%.1f s of CPU work)'
                   % (n, renderer.img_shape[1], renderer.img_shape[0], dt),
-    }, flops_per_sample
+    }, flops_per_sample, mesh_bytes_per_sample
 
 
 def main():
@@ -96,9 +99,18 @@ def main():
 
     from raytracer_amd.renderer import Renderer
     width, height = (int(v) for v in args.size.lower().split('x'))
-    scene = runpy.run_path(os.path.join(ROOT, 'raytracer_amd', 'scenes', args.scene + '.py'))['scene']
-    scene.image.size = (width, height)
-    scene.samples_per_pixel = (args.steps + args.warmup) * args.passes_per_step * world
+
+    def load_scene(layout='flat'):
+        path = os.path.join(ROOT, 'raytracer_amd', 'scenes', args.scene + '.py')
+        if args.scene == 'scene-mesh':
+            n_u, n_v = (int(v) for v in args.mesh_grid.lower().split('x'))
+            scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout)
+        else:
+            scene = runpy.run_path(path)['scene']
+        scene.image.size = (width, height)
+        scene.samples_per_pixel = (args.steps + args.warmup) * args.passes_per_step * world
+        return scene
+    scene = load_scene()
 
     ray_range = None
     if args.partition == 'tiles' and world > 1:
@@ -155,8 +167,8 @@ def main():
         'scaling': 'strong' if tiles else 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s %dx%d, %d sample passes per step (RGB, next-event light, '
-                               'max_bounces %d), broadcast random tape, parity build '
-                               '(-ffp-contract=off)' % (args.scene, width, height, P, scene.max_bounces),
+                               'max_bounces %d), broadcast random tape, build options %s'
+                               % (args.scene, width, height, P, scene.max_bounces, ' '.join(r.build_options)),
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'parallelism': ('%s x%d, one all-reduce' % ('tile-partitioned' if tiles else 'pass-striped', world))
                                   if world > 1 else 'single GPU'},
@@ -165,22 +177,39 @@ def main():
         final = frame.cpu().numpy()
         assert np.isfinite(final).all() and final[:, :3].mean() > 0, "bad image"
         result['image_mean'] = float(final[:, :3].mean() / (P * args.steps * (1 if tiles else world)))
-        flops_per_sample = None
+        flops_per_sample = mesh_bytes = None
         if world == 1 and not args.no_cpu_baseline:
-            base, flops_per_sample = cpu_baseline(r, tape, args.cpu_seconds)
+            oracle_renderer = r
+            if args.scene == 'scene-mesh':
+                # the oracle walks the reference's octree stream: same tree, other serialisation
+                oracle_renderer = Renderer(load_scene('stream'), seed=args.seed, device=False)
+            base, flops_per_sample, mesh_bytes = cpu_baseline(oracle_renderer, tape, args.cpu_seconds)
             result['cpu_baseline'] = base
         avg_ms = float(np.mean(kernel_ms))
-        roof = {'bound': 'valu', 'kernel': 'clr_render', 'unit': 'TFLOP/s',
-                'peak': PEAK_FP32_VECTOR_TFLOPS, 'peak_unpacked_fma': PEAK_FP32_SCALAR_FMA_TFLOPS,
-                'kernel_ms_avg': avg_ms, 'traffic': None}
-        if flops_per_sample is not None:
-            achieved = flops_per_sample * r.n_pixels * P / (avg_ms * 1e-3) / 1e12
-            roof.update({'achieved': achieved, 'frac': achieved / PEAK_FP32_VECTOR_TFLOPS,
-                         'frac_unpacked_fma': achieved / PEAK_FP32_SCALAR_FMA_TFLOPS,
-                         'flops_per_sample': flops_per_sample})
+        launch_samples = float(r.n_pixels) * P
+        if mesh_bytes:
+            # mesh traversal: HBM roofline on the algorithmic bytes of the flattened layout
+            # (8 B per node record visited, 48 B per triangle test)
+            achieved = mesh_bytes * launch_samples / (avg_ms * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'kernel': 'clr_render', 'unit': 'GB/s', 'peak': PEAK_HBM_GBS,
+                    'achieved': achieved, 'frac': achieved / PEAK_HBM_GBS,
+                    'mesh_bytes_per_sample': mesh_bytes, 'flops_per_sample': flops_per_sample}
+        else:
+            roof = {'bound': 'valu', 'kernel': 'clr_render', 'unit': 'TFLOP/s',
+                    'peak': PEAK_FP32_VECTOR_TFLOPS, 'peak_unpacked_fma': PEAK_FP32_SCALAR_FMA_TFLOPS}
+            if flops_per_sample is not None:
+                achieved = flops_per_sample * launch_samples / (avg_ms * 1e-3) / 1e12
+                roof.update({'achieved': achieved, 'frac': achieved / PEAK_FP32_VECTOR_TFLOPS,
+                             'frac_unpacked_fma': achieved / PEAK_FP32_SCALAR_FMA_TFLOPS,
+                             'flops_per_sample': flops_per_sample})
+        roof['kernel_ms_avg'] = avg_ms
+        roof['traffic'] = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
-            roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            # HBM bytes per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE of this same command
+            # (tools/profile.sh + tools/summarize_profile.py); keyed by scene and launch shape
+            key = '%s %dx%d p%d' % (args.scene, width, height, P)
+            roof['traffic'] = json.load(open(pmc)).get(key)
         result['roofline'] = roof
         print(json.dumps(result))
     if world > 1:

@@ -27,9 +27,13 @@ typedef struct { float x, y, z, w; } vec4;
 
 #ifdef ORC_COUNT_FLOPS
 static __thread double orc_flops;
+static __thread double orc_mesh_bytes;      /* algorithmic mesh bytes, flattened layout: 8 B per node visited, 48 B per triangle test */
+static double orc_mesh_bytes_total;
 #define FL(n) (orc_flops += (n))
+#define MB(n) (orc_mesh_bytes += (n))
 #else
 #define FL(n) ((void)0)
+#define MB(n) ((void)0)
 #endif
 
 #define PI_F 3.14159274101257324f
@@ -285,6 +289,7 @@ static inline void triangle_test(const float *vd, const int *idata, int face_ind
     const int v1i = idata[3 * face_index], v2i = idata[3 * face_index + 1], v3i = idata[3 * face_index + 2];
     const vec3 v1 = v3p(vd + 4 * v1i), v2 = v3p(vd + 4 * v2i), vv3 = v3p(vd + 4 * v3i);
     const vec3 e1 = sub3(v2, v1), e2 = sub3(vv3, v1);
+    MB(48);
     const vec3 P = cross3(ray, e2);
     const float det = dot3(e1, P);
     const float inv_det = 1.f / det;
@@ -379,6 +384,7 @@ static void octree_tracer(const orc_scene *sc, const orc_object *o, vec3 origin,
         while ((int)depth < levels - 1) {       /* descend to the leaf holding ray_pos */
             child_mask = octree_data[path[depth]];
             data_ptr = octree_data[path[depth] + 1];
+            MB(8);
             node_origin = add3(root_origin, scale3(v3((float)ocx, (float)ocy, (float)ocz), node_size));
             if (child_mask == 0 || child_mask == 0x100) break;
             const vec3 rel_coords = sub3(ray_pos, node_origin);
@@ -439,6 +445,7 @@ static void octree_tracer(const orc_scene *sc, const orc_object *o, vec3 origin,
         if (lcy > 0) child_idx += 2;
         if (lcz > 0) child_idx += 1;
         data_ptr = octree_data[path[depth - 1] + 1];
+        MB(4);
         path[depth] = data_ptr + child_idx * 2;
 
         isec_begin = isec_end;
@@ -965,14 +972,15 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
                int n_threads, double *flops) {
     const int stride = sc->n_objects + 1;
     const int row_len = 10 * stride;
-    double total_flops = 0.0;
+    double total_flops = 0.0, total_bytes = 0.0;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
-    #pragma omp parallel for schedule(dynamic, 256) reduction(+ : total_flops)
+    #pragma omp parallel for schedule(dynamic, 256) reduction(+ : total_flops, total_bytes)
     for (int k = 0; k < n_pixels; ++k) {
 #ifdef ORC_COUNT_FLOPS
         orc_flops = 0.0;
+        orc_mesh_bytes = 0.0;
 #endif
         const vec3 base_ray = v3p(cam + 4 * k);
         vec3 acc = v3p(img + 4 * k);
@@ -992,8 +1000,12 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
         img[4 * k] = acc.x; img[4 * k + 1] = acc.y; img[4 * k + 2] = acc.z;
 #ifdef ORC_COUNT_FLOPS
         total_flops += orc_flops;
+        total_bytes += orc_mesh_bytes;
 #endif
     }
+#ifdef ORC_COUNT_FLOPS
+    orc_mesh_bytes_total = total_bytes;
+#endif
     if (flops) *flops = total_flops;
     return 0;
 }
@@ -1026,3 +1038,12 @@ int orc_first_hit(const orc_scene *sc, const float *cam, const float *pass_tape,
 float orc_math_exp(float x) { return clr_expf(x); }
 float orc_math_log(float x) { return clr_logf(x); }
 float orc_math_tan(float x) { return clr_tanf(x); }
+
+/* algorithmic mesh bytes of the last orc_render call (counting build only, else 0) */
+double orc_last_mesh_bytes(void) {
+#ifdef ORC_COUNT_FLOPS
+    return orc_mesh_bytes_total;
+#else
+    return 0.0;
+#endif
+}

@@ -316,6 +316,8 @@ class OracleScene:
                             rows_p, r.n_pixels, n, _fptr(img), _fptr(dump) if dump is not None else None,
                             n_threads, ctypes.byref(flops))
         assert rc == 0
+        lib.orc_last_mesh_bytes.restype = ctypes.c_double
+        self.last_mesh_bytes = lib.orc_last_mesh_bytes()
         return img, dump, flops.value
 
     def first_hit(self, tape, n_threads=0):

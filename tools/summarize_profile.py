@@ -20,7 +20,7 @@ SRC = os.path.join(ROOT, 'gpurun_out', 'prof')
 DST = os.path.join(ROOT, 'profiles')
 
 
-def main(tag):
+def main(tag, key):
     os.makedirs(DST, exist_ok=True)
     stats = glob.glob(os.path.join(SRC, 'trace', '*', '*_kernel_stats.csv'))[0]
     shutil.copy(stats, os.path.join(DST, tag + '_kernel_stats.csv'))
@@ -60,10 +60,13 @@ def main(tag):
             summary['valu_lane_utilisation'] = c['SQ_THREAD_CYCLES_VALU'] / (c['SQ_ACTIVE_INST_VALU'] * 64.0) \
                 if c['SQ_ACTIVE_INST_VALU'] else None
     json.dump(summary, open(os.path.join(DST, tag + '_clr_render.json'), 'w'), indent=1)
-    json.dump({'hbm_bytes_per_launch': fetch + write, 'source': tag + '_clr_render.json'},
-              open(os.path.join(DST, 'pmc_traffic.json'), 'w'))
+    path = os.path.join(DST, 'pmc_traffic.json')
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    table[key] = fetch + write
+    json.dump(table, open(path, 'w'), indent=1)
     print(json.dumps(summary, indent=1))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'r01')
+    main(sys.argv[1] if len(sys.argv) > 1 else 'r01',
+         sys.argv[2] if len(sys.argv) > 2 else 'scene-dev 1920x1080 p32')
