@@ -94,7 +94,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP back end has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # CLRAY_FORCE_DIST=1 exercises the RCCL code path with a single rank (development check)
+    use_dist = world > 1 or bool(os.environ.get('CLRAY_FORCE_DIST'))
+    if use_dist:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from raytracer_amd.renderer import Renderer
@@ -136,12 +138,12 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for w in range(args.warmup):
         r.render_resident(w * P, P)
-    if world > 1:
+    if use_dist:
         warm = frame.clone()
         dist.all_reduce(warm)          # set up the communicator outside the timed region
     frame.zero_()
@@ -150,11 +152,11 @@ def main():
     kernel_ms = []
     for k in range(args.steps):
         kernel_ms.append(r.render_resident((args.warmup + k) * P, P))
-    if world > 1:
+    if use_dist:
         dist.all_reduce(frame)         # sum of private accumulators / gather of disjoint tiles
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -212,7 +214,7 @@ def main():
             roof['traffic'] = json.load(open(pmc)).get(key)
         result['roofline'] = roof
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
