@@ -43,3 +43,21 @@ def test_name_clash_is_an_error():
 
 def test_parity_options_disable_contraction():
     assert '-ffp-contract=off' in hip_compiler.PARITY_OPTIONS
+
+
+def test_empty_scene_still_generates_a_program():
+    from raytracer_amd.scenes.default_scenes import BoxScene
+    scene = BoxScene()
+    scene.objects[:] = []
+    scene.image.size = (16, 8)
+    r = Renderer(scene, device=False, seed=0)
+    assert accelerator.compile_only(r.program_code, r.build_options) > 1000
+
+
+def test_large_scenes_keep_parameters_in_constant_memory():
+    """More than 48 objects: the parameter table is filled at run time instead of baked."""
+    r = Renderer(load_scene('scene-stairs-small', (16, 8)), device=False, seed=0)
+    assert r.bake_parameters and '0x1' in r.program_code
+    big = Renderer(load_scene('scene-stairs-small', (16, 8)), device=False, seed=0, bake_parameters=False)
+    assert '__constant__ float4 clr_params[' in big.program_code
+    assert accelerator.compile_only(big.program_code, big.build_options) > 1000
