@@ -189,7 +189,7 @@ def main():
             result['cpu_baseline'] = base
         avg_ms = float(np.mean(kernel_ms))
         launch_samples = float(r.n_pixels) * P
-        if mesh_bytes:
+        if mesh_bytes and args.scene == 'scene-mesh':
             # mesh traversal: HBM roofline on the algorithmic bytes of the flattened layout
             # (8 B per node record visited, 48 B per triangle test)
             achieved = mesh_bytes * launch_samples / (avg_ms * 1e-3) / 1e9
