@@ -160,7 +160,10 @@ static void c_cylinder(vec3 origin, vec3 ray, float *b, float *e, vec3 axis, flo
         rr = R * R;
         FL(1);
     }
-    float discr = dotp * dotp - ray_perp2 * (perp2 - rr);
+    float discr;
+    /* ZCylinderComponent.cl:14 has the double literal 1.0: product and difference in binary64 */
+    if (z_variant) discr = (float)((double)(dotp * dotp) - (double)ray_perp2 * ((double)perp2 - 1.0));
+    else discr = dotp * dotp - ray_perp2 * (perp2 - rr);
     FL(5);
     if (discr < 0) { *b = 1; *e = 0; return; }
     float sq = sqrtf(discr);
@@ -512,7 +515,7 @@ static void qjs2_tracer(const orc_object *o, vec3 origin, vec3 ray, float old_is
             FL(8);
         }
         float l = sqrtf(dot4(q, q));
-        step = 0.5f * l * clr_logf(l) / sqrtf(dot4(qd, qd));
+        step = (float)(0.5 * (double)l * (double)clr_logf(l) / (double)sqrtf(dot4(qd, qd)));   /* QuaternionJuliaSet2.cl:61, double literal */
         step = fminf(step, MAX_STEP);
         FL(8);
         (void)gr; (void)gi; (void)gj; (void)gk;

@@ -26,7 +26,8 @@
                 q = quaternion_square(q) + c;
             }
             float l = length(q);
-            step = 0.5f * l * clr_logf(l) / length(qd);
+            // `0.5 * l * log(l) / length(qd)` with a double literal: one rounding at the end
+            step = (float)(0.5 * (double)l * (double)clr_logf(l) / (double)length(qd));
             step = fminf(step, MAX_STEP);
             if (step < TARGET_EPS) {
                 *t_hit = dist + step;

@@ -8,7 +8,10 @@
         float half_b = dot(d_perp, o_perp);
         float o_perp2 = dot(o_perp, o_perp);
         float d_perp2 = dot(d_perp, d_perp);
-        float disc = half_b*half_b - d_perp2*(o_perp2 - 1.0f);
+        // the reference writes `perp2 - 1.0` with a double literal, so on a double-capable OpenCL
+        // device the product and the difference are formed in binary64 and rounded once; the
+        // discriminant is ill-conditioned for distant rays, so this is kept
+        float disc = (float)((double)(half_b*half_b) - (double)d_perp2*((double)o_perp2 - 1.0));
         if (disc < 0) {
             *t_enter = 1;
             *t_exit = 0;

@@ -210,7 +210,7 @@ def test_bad_arguments_are_rejected():
         r.acc.render_passes(RenderArgs(n_pixels=10, n_passes=1))
 
 
-@pytest.mark.parametrize('name', SCENES)
+@pytest.mark.parametrize('name', SCENES + ['variant-camera', 'variant-media'])
 def test_hip_against_reference_golden(name):
     """HIP directly against the fixtures made from the reference's own device code
     (tests/test_golden.py explains the fixtures and the bars)."""
@@ -282,3 +282,29 @@ def test_run_time_parameter_table_bit_exact():
     r.render_tape(tape)
     oimg, _, _ = oracle.OracleScene(r).render(tape)
     assert np.array_equal(bits(r.img.get()), bits(oimg))
+
+
+def test_generic_launch_and_buffer_helpers():
+    """Accelerator.call (clr_launch) and the array helpers, the analogue of the reference's
+    per-kernel launch interface (accelerator.py:63-153): launching clr_first_hit by name gives
+    the same result as the dedicated entry point."""
+    r = Renderer(load_scene('scene-dev', (64, 48)), seed=3)
+    acc = r.acc
+    tape = r.make_tape(0, 1)
+    ids_ref, t_ref, _ = r.first_hit(tape)
+    ids = acc.new_array((r.n_pixels, 2), np.int32, zeros=True)
+    t = acc.new_array((r.n_pixels,), np.float32)
+    t.fill(-1.0)
+    assert (t.get() == -1.0).all()
+    normal = acc.new_vec3_array((r.n_pixels,))
+    acc.call('clr_first_hit', r.n_pixels,
+             (r.cam, r.dev_pass_tape, r.dev_vector_data, r.dev_integer_data),
+             value_args=(np.int32(r.n_pixels), ids, t, normal))
+    assert np.array_equal(ids.get(), ids_ref) and np.array_equal(t.get(), t_ref)
+    assert 'clr_first_hit' in acc.profiling_info and acc.profiling_info['clr_first_hit']['n'] == 1
+    # slices are views of the same device memory
+    t[:16].fill(7.0)
+    host = t.get()
+    assert (host[:16] == 7.0).all() and np.array_equal(host[16:], t_ref[16:])
+    with pytest.raises(Exception):
+        acc.call('no_such_kernel', 1, ())

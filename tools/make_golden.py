@@ -38,6 +38,9 @@ import types
 
 import numpy as np
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import golden_scenes  # noqa: E402  (scene descriptions shared with the tests)
+
 REFERENCE = '/root/reference'
 WORK = '/tmp/clray_golden'
 REF3 = os.path.join(WORK, 'ref3')
@@ -267,7 +270,15 @@ def make_fixture(scene_name, size, n_passes, seed):
     np.random.seed(seed)
     for mod in [m for m in sys.modules if m == scene_name]:
         del sys.modules[mod]
-    scene = __import__(scene_name).scene
+    if scene_name in golden_scenes.VARIANTS:
+        import types as _types
+        import objects as ref_objects
+        from scenes.default_scenes import BoxScene as RefBoxScene
+        api = _types.SimpleNamespace(BoxScene=RefBoxScene, Sphere=ref_objects.Sphere,
+                                     Cylinder=ref_objects.Cylinder, HalfSpace=ref_objects.HalfSpace)
+        scene = golden_scenes.VARIANTS[scene_name](api)
+    else:
+        scene = __import__(scene_name).scene
     scene.image.size = size
     scene.samples_per_pixel = max(n_passes, 4)
     args = types.SimpleNamespace(choose_opencl_context=False, cl_build_options=[])
@@ -372,7 +383,7 @@ def make_fixture(scene_name, size, n_passes, seed):
 
 
 def main():
-    names = sys.argv[1:] or ['scene-dev', 'scene-three-objects', 'scene-test']
+    names = sys.argv[1:] or ['scene-dev', 'scene-three-objects', 'scene-test', 'variant-camera', 'variant-media']
     os.makedirs(OUT, exist_ok=True)
     for name in names:
         size = (64, 48) if name != 'scene-test' else (64, 48)
