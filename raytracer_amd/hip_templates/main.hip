@@ -185,7 +185,7 @@ CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last,
 //              identical in both modes: a lane still visits its passes and segments in order.
 // dbg (optional, n_passes == 1): CLR_DBG_STRIDE float4 per (segment, pixel).
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_per_simd if renderer.min_waves_per_simd else '' }})
 clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
            const float4 * __restrict__ pass_tape, const float4 * __restrict__ bounce_tape,
            const float * __restrict__ material_rows,

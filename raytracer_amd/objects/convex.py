@@ -1,0 +1,309 @@
+"""Convex bodies as intersections of components.
+
+ConvexIntersection and its component classes (half-space, slab, sphere, infinite cylinder,
+semi-infinite cone), the literal-baking Unique/Fixed variants, and the shapes built from them:
+Cylinder, Cone, Parallelepiped and the Platonic solids.  Same constructors as the reference's
+objects/convex_intersection.py:5-120, planes.py:23-54, sphere.py:39-49, cylinder.py:5-39,
+cone.py:5-43 and polyhedra.py:5-102."""
+import math
+import numpy
+from .base import Tracer, next_unique_id
+from ..geometry import normalize_tuple, vec_norm
+from ..geometry import Affine, rotation_aligning_vectors
+
+def float_literal(value):
+    """A C float literal for a baked-in scalar."""
+    text = repr(float(value))
+    if 'e' not in text and '.' not in text and 'inf' not in text and 'nan' not in text:
+        text += '.0'
+    return text + 'f'
+
+
+def vec_literal(vec):
+    return "make_vec3(%s)" % ", ".join(float_literal(c) for c in numpy.ravel(vec))
+
+
+class ConvexIntersection(Tracer):
+    """Intersection of convex bodies; run-time parameters, one function per component list."""
+
+    class Component(Tracer):
+        def __init__(self, pos=(0, 0, 0)):
+            Tracer.__init__(self, position=pos)
+
+    def __init__(self, origin, components):
+        Tracer.__init__(self, position=origin)
+        self.components = components
+        self.unique_tracer_id = '_' + '_'.join(c.__class__.__name__ for c in components)
+
+    def template_name(self):
+        return 'ConvexIntersection'
+
+    def make_functions(self, template_env):
+        funcs = dict(Tracer.make_functions(self, template_env))
+        for component in self.components:
+            funcs.update(component.make_functions(template_env))
+        return funcs
+
+    @property
+    def convex(self):
+        return True
+
+    # ---- template helpers
+    def face_ranges(self):
+        """[(component index, component, first face id, end face id)]: the faces ("subobjects")
+        of the components are numbered consecutively from 1, 0 meaning "no face"."""
+        ranges, first = [], 0
+        for i, c in enumerate(self.components):
+            ranges.append((i, c, first, first + c.n_subobjects))
+            first += c.n_subobjects
+        return ranges
+
+    def component_position_expr(self, component_idx, base):
+        return '%s - _pos_%d' % (base, component_idx)
+
+    def component_parameter_string(self, component_idx):
+        names = self.components[component_idx].parameter_names()
+        return ''.join(', %s_%d' % (n, component_idx) for n in names)
+
+    def component_tracer_call_params(self, component_idx):
+        return '%s, ray, &c_enter, &c_exit, &c_face, inside%s' % (
+            self.component_position_expr(component_idx, 'rel'),
+            self.component_parameter_string(component_idx))
+
+    def component_normal_call_params(self, component_idx, subobject_offset):
+        return '%s, subobject - %d, p_normal%s' % (
+            self.component_position_expr(component_idx, 'p'), subobject_offset,
+            self.component_parameter_string(component_idx))
+
+    # ---- run-time parameters: component position + the component's own parameters
+    def parameter_declarations(self):
+        decls = []
+        for i, c in enumerate(self.components):
+            decls.append('float3 _pos_%d' % i)
+            decls += ['%s_%d' % (d, i) for d in c.parameter_declarations()]
+        return decls
+
+    def parameter_values(self):
+        values = []
+        for c in self.components:
+            values.append(c.position)
+            values += c.parameter_values()
+        return values
+
+
+class UniqueConvexIntersection(ConvexIntersection):
+    """All component parameters baked into the generated source as literals."""
+
+    def __init__(self, origin, components):
+        ConvexIntersection.__init__(self, origin, components)
+        self.unique_tracer_id = next_unique_id()
+
+    def parameter_declarations(self):
+        return []
+
+    def parameter_values(self):
+        return []
+
+    def component_position_expr(self, component_idx, base):
+        pos = self.components[component_idx].position
+        if numpy.linalg.norm(pos) < 1e-10:
+            return base
+        return '%s - %s' % (base, vec_literal(pos))
+
+    def component_parameter_string(self, component_idx):
+        parts = []
+        for val in self.components[component_idx].parameter_values():
+            parts.append(vec_literal(val) if numpy.size(val) > 1 else float_literal(val))
+        return ''.join(', ' + p for p in parts)
+
+
+class FixedConvexIntersection(UniqueConvexIntersection):
+    """Baked literals shared by every instance of the subclass (pose via the affine only)."""
+
+    def __init__(self, *args, **kwargs):
+        UniqueConvexIntersection.__init__(self, *args, **kwargs)
+        self.unique_tracer_id = ''
+
+
+# ---------------------------------------------------------------- components
+
+class HalfSpaceComponent(ConvexIntersection.Component):
+    n_subobjects = 1
+
+    def __init__(self, normal, h):
+        ConvexIntersection.Component.__init__(self)
+        self.normal = normalize_tuple(normal)
+        self.h = h
+
+    def parameter_declarations(self):
+        return ['float3 normal', 'float h']
+
+
+class LayerComponent(HalfSpaceComponent):
+    """Infinite slab of thickness h along ``axis`` (h defaults to |axis|)."""
+    n_subobjects = 2
+
+    def __init__(self, axis, h=None):
+        HalfSpaceComponent.__init__(self, axis, vec_norm(axis) if h is None else h)
+
+
+class ZLayerComponent(LayerComponent):
+    def __init__(self):
+        LayerComponent.__init__(self, (0, 0, 1), 1.0)
+
+    def parameter_declarations(self):
+        return []
+
+
+class SphereComponent(ConvexIntersection.Component):
+    n_subobjects = 1
+
+    def __init__(self, pos, R):
+        ConvexIntersection.Component.__init__(self, pos)
+        self.R = R
+
+    def parameter_declarations(self):
+        return ['float R']
+
+
+class CylinderComponent(ConvexIntersection.Component):
+    n_subobjects = 1
+
+    def __init__(self, axis, R):
+        ConvexIntersection.Component.__init__(self)
+        self.axis = normalize_tuple(axis)
+        self.R = R
+
+    def parameter_declarations(self):
+        return ['float3 axis', 'float R']
+
+
+class ZCylinderComponent(CylinderComponent):
+    def __init__(self):
+        CylinderComponent.__init__(self, (0, 0, 1), 1.0)
+
+    def parameter_declarations(self):
+        return []
+
+
+class ConeComponent(ConvexIntersection.Component):
+    n_subobjects = 1
+
+    def __init__(self, pos, axis, slope):
+        ConvexIntersection.Component.__init__(self, pos)
+        self.axis = normalize_tuple(axis)
+        self.slope = slope
+
+    def parameter_declarations(self):
+        return ['float3 axis', 'float slope']
+
+
+class ZConeComponent(ConeComponent):
+    def __init__(self):
+        ConeComponent.__init__(self, (0, 0, 0), (0, 0, 1), 1.0)
+
+    def parameter_declarations(self):
+        return []
+
+
+# ---------------------------------------------------------------- composed shapes
+
+class Cylinder(FixedConvexIntersection):
+    """Unit z-slab ∩ unit z-cylinder, posed by rotation(axis) ∘ scale(R, R, height)."""
+
+    def __init__(self, bottom_center, axis, height, R):
+        self.axis = axis
+        self.height = height
+        self.R = R
+        FixedConvexIntersection.__init__(self, bottom_center,
+                                         [ZLayerComponent(), ZCylinderComponent()])
+
+    def tracer_coordinate_system(self):
+        rotation = Affine(linear=rotation_aligning_vectors((0, 0, 1), self.axis))
+        return rotation(Affine(scaling=(self.R, self.R, self.height)))
+
+
+class Cone(FixedConvexIntersection):
+    """{z <= 1} ∩ unit z-cone with its tip at the origin, posed like Cylinder."""
+
+    def __init__(self, tip, axis, height, R):
+        self.axis = axis
+        self.height = height
+        self.R = R
+        FixedConvexIntersection.__init__(self, tip, [
+            HalfSpaceComponent(normal=(0, 0, 1), h=1.0), ZConeComponent()])
+
+    def tracer_coordinate_system(self):
+        rotation = Affine(linear=rotation_aligning_vectors((0, 0, 1), self.axis))
+        return rotation(Affine(scaling=(self.R, self.R, self.height)))
+
+
+PHI = 0.5 * (1 + math.sqrt(5))  # golden ratio
+
+
+class Parallelepiped(ConvexIntersection):
+    def __init__(self, origin, ax1, ax2, ax3):
+        ConvexIntersection.__init__(self, origin, [LayerComponent(ax) for ax in (ax1, ax2, ax3)])
+        self.unique_tracer_id = ''
+
+
+class HyperplaneRepresentation(FixedConvexIntersection):
+    """Polyhedron given by outward plane vectors p (plane at distance |p| along p)."""
+
+    def __init__(self, center, planes, R):
+        FixedConvexIntersection.__init__(
+            self, center, [HalfSpaceComponent(p, vec_norm(p)) for p in planes])
+        self.linear_transform(scaling=R)
+
+
+class SymmetricDualPolyhedron(FixedConvexIntersection):
+    """Dual of the point-symmetric vertex set {±v}: one slab per listed vertex."""
+
+    def __init__(self, center, vertices, R):
+        slabs = []
+        for v in vertices:
+            slab = LayerComponent(tuple(-x for x in v), vec_norm(v) * 2.0)
+            slab.position = v
+            slabs.append(slab)
+        FixedConvexIntersection.__init__(self, center, slabs)
+        self.linear_transform(scaling=R)
+
+
+class Tetrahedron(HyperplaneRepresentation):
+    def __init__(self, center, R):
+        q = 1.0 / math.sqrt(2)
+        HyperplaneRepresentation.__init__(
+            self, center, [(1, 0, -q), (-1, 0, -q), (0, 1, q), (0, -1, q)], R / (q + 1 / q))
+
+
+class Cube(SymmetricDualPolyhedron):
+    def __init__(self, center, side=None, R=None):
+        if side is None:
+            # as in the reference, calling with neither argument is a TypeError (R is None)
+            side = R / math.sqrt(3) * 2.0
+        SymmetricDualPolyhedron.__init__(
+            self, center, [(1, 0, 0), (0, 1, 0), (0, 0, 1)], side / 2.0)
+
+
+class Octahedron(SymmetricDualPolyhedron):
+    def __init__(self, center, R):
+        SymmetricDualPolyhedron.__init__(
+            self, center, [(1, 1, 1), (1, -1, 1), (-1, 1, 1), (-1, -1, 1)], R / 3.0)
+
+
+class Dodecahedron(SymmetricDualPolyhedron):
+    def __init__(self, center, R):
+        SymmetricDualPolyhedron.__init__(
+            self, center,
+            [(0, 1, PHI), (1, PHI, 0), (PHI, 0, 1), (0, -1, PHI), (-1, PHI, 0), (PHI, 0, -1)],
+            R / (PHI + 1.0 / PHI))
+
+
+class Icosahedron(SymmetricDualPolyhedron):
+    def __init__(self, center, R):
+        q = 1 / PHI
+        SymmetricDualPolyhedron.__init__(
+            self, center,
+            [(1, 1, 1), (-1, 1, 1), (1, -1, 1), (-1, -1, 1), (0, q, PHI), (0, -q, PHI),
+             (q, PHI, 0), (-q, PHI, 0), (PHI, 0, q), (PHI, 0, -q)],
+            R / (PHI + 1 / PHI ** 3))

@@ -1,11 +1,10 @@
-"""Implicit surfaces f(x,y,z) = 0 traced with interval arithmetic.
-
-Same constructor and code-generation role as /root/reference/objects/implicit_surface.py:6-131:
-sympy differentiates the equation and two printers turn it into (a) an interval-arithmetic
-expression in the ``ia_*`` helpers for f and df/dt along the ray and (b) plain float
-expressions for the gradient.  The equation must be positive outside the body.
-"""
-from ..tracer import Tracer, next_unique_id
+"""Ray-marched shapes: ImplicitSurface (sympy-generated interval arithmetic), the two quaternion
+Julia sets and DistanceField (user code string).  Same constructors as the reference's
+objects/implicit_surface.py:6-131, julia_sets.py:7-41 and distance_field.py:3-17.
+The equation of an ImplicitSurface must be positive outside the body; a DistanceField's
+``tracer_code`` assigns ``dist`` from the local coordinates ``x, y, z``."""
+from .base import Tracer, next_unique_id
+from .convex import float_literal
 
 
 def _printers():
@@ -88,6 +87,8 @@ class ImplicitSurface(Tracer):
         return 'ImplicitSurface'
 
     def f_code_template(self):
+        """Key of a hand-written interval function in shapes/marching.hip that replaces the
+        sympy-printed one (None = use f_code / df_code)."""
         return None
 
     def compute_f_code(self):
@@ -95,3 +96,56 @@ class ImplicitSurface(Tracer):
 
     def compute_df_code(self):
         return "\n            df = %s; " % self._interval_printer.doprint(self.derivative)
+
+
+class QuaternionJuliaSet(ImplicitSurface):
+    """Interval-arithmetic root isolation on f = |z_n|^2 - 4, z -> z^2 + c."""
+
+    def __init__(self, c, julia_itr, *args, **argd):
+        self.c = c
+        self.julia_itr = julia_itr
+        argd['bndR'] = 1.5
+        argd['self_intersection'] = False
+        ImplicitSurface.__init__(self, "x^2 + y^2 + z^2 - 1", *args, **argd)
+
+    def f_code_template(self):
+        return 'QuaternionJuliaSet'
+
+    def compute_f_code(self):
+        self.c_code = [float_literal(x) for x in self.c]
+
+    def compute_df_code(self):
+        pass
+
+
+class QuaternionJuliaSet2(Tracer):
+    """Distance-estimator marching (Hart et al. 1989)."""
+
+    def __init__(self, c, julia_itr, center=(0, 0, 0), scale=1.0, **kwargs):
+        Tracer.__init__(self, position=center, scaling=scale)
+        self.c = c
+        self.julia_itr = julia_itr
+        self.bndR = 4.0
+        self.max_itr = 100
+        self.precision = 0.001
+        self.max_step = 0.1
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def c_as_float4(self):
+        return "make_vec4(%s)" % ", ".join(float_literal(x) for x in self.c)
+
+
+class DistanceField(Tracer):
+
+    def __init__(self, tracer_code, normal_code=None, center=(0, 0, 0), bndR=None,
+                 max_itr=1000, precision=1e-5, self_intersection=True):
+        Tracer.__init__(self, position=center)
+        self.max_itr = max_itr
+        self.precision = precision
+        self.bndR = bndR
+        self.no_self_intersection = not self_intersection
+        self.tracer_code = tracer_code.strip()
+        self.normal_code = normal_code
+        self.unique_tracer_id = next_unique_id()

@@ -1,4 +1,5 @@
-"""Octree over a TriangleMesh (reference objects/octree.py:4-233).
+"""TriangleMesh (every face tested, reference objects/triangle_mesh.py:5-117) and Octree over a
+TriangleMesh (reference objects/octree.py:4-233).
 
 ``build()`` restates the reference's breadth-first construction (bounding-sphere and
 face-plane overlap test per node, leaf when few "small" faces remain or at max depth) with a
@@ -9,7 +10,93 @@ root header last).  Face indices are tracked explicitly, so the reference's late
 whenever no face drops out of the active set, e.g. the scene-test cube.
 """
 import numpy
-from ..tracer import Tracer
+from .base import Tracer
+
+
+def to_vector_array(array_of_arrays, dtype=numpy.float32):
+    arr = numpy.array(array_of_arrays, dtype=dtype)
+    if arr.ndim != 2 or arr.shape[-1] != 3:
+        raise RuntimeError('invalid shape %s' % (arr.shape,))
+    return arr
+
+
+def generate_smooth_normals(vertices, faces):
+    """Per-vertex mean of the unit normals of the incident faces (unreferenced vertices: (1,1,1))."""
+    v = vertices.astype(numpy.float32)
+    tri = v[faces]
+    face_n = numpy.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    face_n = face_n / numpy.sqrt(numpy.sum(face_n ** 2, axis=1))[:, None]
+    sums = numpy.zeros(v.shape, dtype=numpy.float64)
+    counts = numpy.zeros(v.shape[0], dtype=numpy.int64)
+    for corner in range(3):
+        numpy.add.at(sums, faces[:, corner], face_n)
+        numpy.add.at(counts, faces[:, corner], 1)
+    normals = numpy.ones(v.shape)
+    used = counts > 0
+    mean = sums[used] / counts[used][:, None]
+    normals[used] = mean / numpy.sqrt(numpy.sum(mean ** 2, axis=1))[:, None]
+    return normals
+
+
+class TriangleMesh(Tracer):
+
+    def __init__(self, vertices, faces, normals=None, center=(0, 0, 0), scale=1.0,
+                 auto_scale=False, auto_flip_normal=False, shading='flat',
+                 auto_smooth_normals=False):
+        center = numpy.reshape(numpy.array(center), (1, 3))
+        self.vertices = to_vector_array(vertices)
+        self.faces = to_vector_array(faces, dtype=numpy.int32)
+        if auto_scale:
+            current_center, current_size = self.get_bounding_cube()
+            self.vertices = self.vertices - current_center[numpy.newaxis, :]
+            if current_size > 0.0:
+                scale = scale / float(current_size * 0.5)
+        Tracer.__init__(self, position=center, scaling=scale)
+        self._auto_flip_normal = auto_flip_normal
+        self.shading = shading
+        self.unique_tracer_id = '_%s_autoflip_%s' % (shading, auto_flip_normal)
+        if shading != 'flat':
+            if auto_smooth_normals:
+                normals = generate_smooth_normals(self.vertices, self.faces)
+            self.normals = to_vector_array(normals)
+            assert self.normals.shape[0] == self.vertices.shape[0]
+        else:
+            assert normals is None
+            self.normals = None
+
+    @property
+    def auto_flip_normal(self):
+        return self._auto_flip_normal
+
+    def get_data(self):
+        vectors = [self.vertices] if self.normals is None else [self.vertices, self.normals]
+        return {'vector': numpy.vstack(vectors), 'integer': numpy.ravel(self.faces)}
+
+    def get_bounding_box(self):
+        lo = self.vertices.min(axis=0)
+        hi = self.vertices.max(axis=0)
+        return [[lo[i], hi[i]] for i in range(3)]
+
+    def get_bounding_cube(self):
+        box = self.get_bounding_box()
+        center = [sum(r) * 0.5 for r in box]
+        side = max(abs(r[1] - r[0]) for r in box)
+        return numpy.array(center), side
+
+    @property
+    def n_faces(self):
+        return self.faces.shape[0]
+
+    @property
+    def n_vertices(self):
+        return self.vertices.shape[0]
+
+    def parameter_declarations(self):
+        return ['int n_vertices', 'int n_triangles']
+
+    def parameter_values(self):
+        return [self.n_vertices, self.n_faces]
+
 
 EMPTY_HEADER = [0x100, -99999]
 
@@ -227,3 +314,74 @@ def face_planes(vertices, faces):
     normals = numpy.cross(v[faces[:, 1]] - p0, v[faces[:, 2]] - p0)
     normals = normals / numpy.sqrt(numpy.sum(normals ** 2, 1))[:, None]
     return normals, numpy.sum(p0 * normals, 1)
+
+
+# ---------------------------------------------------------------- mesh file readers
+# OFF and Stanford "zipper" (ASCII PLY) readers, polygons fan-triangulated; same functions and
+# return values (vertex list, triangle list) as the reference's mesh_formats.py:3-82.
+def open_or_yield(filename_or_file):
+    if isinstance(filename_or_file, str):
+        with open(filename_or_file, 'r') as f:
+            yield f
+    else:
+        yield filename_or_file
+
+
+def poly_to_triangle_fan(vertices):
+    for k in range(1, len(vertices) - 1):
+        yield [vertices[0], vertices[k], vertices[k + 1]]
+
+
+def _read_polygons(stream, n_faces):
+    triangles = []
+    for _ in range(n_faces):
+        fields = [int(tok) for tok in stream.readline().split()]
+        assert fields[0] == len(fields) - 1
+        triangles.extend(poly_to_triangle_fan(fields[1:]))
+    return triangles
+
+
+def read_off(f):
+    for off in open_or_yield(f):
+        head, sep, rest = off.readline().strip().partition('OFF')
+        if head or sep != 'OFF':
+            raise RuntimeError('not OFF format')
+        rest = rest.strip() or off.readline().strip()
+        n_points, n_faces, _ = (int(tok) for tok in rest.split())
+        vertices = [[float(tok) for tok in off.readline().split()] for _ in range(n_points)]
+        return vertices, _read_polygons(off, n_faces)
+
+
+def read_zipper(f):
+    """The format the Stanford bunny is published in."""
+    for zipper in open_or_yield(f):
+        n_vertices = n_faces = None
+        while True:
+            fields = zipper.readline().strip().split()
+            if not fields:
+                raise RuntimeError("unexpected eof/empty line")
+            if fields[0] == 'element' and fields[1] == 'vertex':
+                n_vertices = int(fields[2])
+            elif fields[0] == 'element' and fields[1] == 'face':
+                n_faces = int(fields[2])
+            elif fields[0] == 'end_header':
+                break
+        vertices = []
+        for _ in range(n_vertices):
+            fields = zipper.readline().strip().split()
+            vertices.append([float(fields[c]) for c in range(3)])
+        return vertices, _read_polygons(zipper, n_faces)
+
+
+def remove_duplicate_faces(faces, verbose=False):
+    seen = set()
+    unique = []
+    for face in faces:
+        key = frozenset(face)
+        if key in seen:
+            if verbose:
+                print("WARNING: removed duplicate face %s" % face)
+            continue
+        seen.add(key)
+        unique.append(face)
+    return unique

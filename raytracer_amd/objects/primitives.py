@@ -1,8 +1,9 @@
-"""Sphere shape, also usable as a next-event-estimation light (reference objects/sphere.py:6-49)."""
+"""Stand-alone analytic shapes: Sphere (also the only next-event light shape) and HalfSpace.
+Constructors as in the reference's objects/sphere.py:6-37 and objects/planes.py:7-21."""
 import numpy
-from ..tracer import Tracer
-from ..transformations import Affine
-from .convex_intersection import ConvexIntersection
+from .base import Tracer
+from ..geometry import normalize_tuple
+from ..geometry import Affine, rotation_aligning_vectors
 
 
 class Sphere(Tracer):
@@ -39,12 +40,18 @@ class Sphere(Tracer):
         return numpy.array(self.position), self.R * 2.0
 
 
-class SphereComponent(ConvexIntersection.Component):
-    n_subobjects = 1
+class HalfSpace(Tracer):
+    """{x : normal.x <= h}; in tracer coordinates the boundary is the plane x = 0."""
 
-    def __init__(self, pos, R):
-        ConvexIntersection.Component.__init__(self, pos)
-        self.R = R
+    def __init__(self, normal, h):
+        Tracer.__init__(self)
+        self.normal = normalize_tuple(normal)
+        self.h = h
 
-    def parameter_declarations(self):
-        return ['float R']
+    def tracer_coordinate_system(self):
+        return Affine(linear=rotation_aligning_vectors((1, 0, 0), self.normal),
+                      translation=-numpy.ravel(self.normal) * self.h)
+
+    @property
+    def convex(self):
+        return True

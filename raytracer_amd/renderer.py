@@ -13,7 +13,8 @@ import itertools
 import math
 import numpy as np
 
-from . import camera, utils
+from . import geometry as camera
+from . import geometry as utils
 from .hip_compiler import Compiler, PARITY_OPTIONS
 from .accelerator import Accelerator, RenderArgs
 
@@ -25,7 +26,8 @@ DEBUG_RECORD = 6     # float4 per (segment, pixel) in the debug dump
 class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
-                 device_index=0, bake_parameters=None, ray_range=None):
+                 device_index=0, bake_parameters=None, ray_range=None,
+                 min_waves_per_simd=None):
         self.scene = scene
         # tile partitioning: (first ray, count) in ray order; a contiguous range of ray
         # indices is a set of 4-pixel-wide column blocks of the frame (get_image_order)
@@ -40,6 +42,8 @@ class Renderer:
         self._init_camera_and_image()
         self._init_materials()
 
+        # optional occupancy hint for the render kernel (second __launch_bounds__ argument)
+        self.min_waves_per_simd = min_waves_per_simd
         # small scenes: bake the per-object parameters into the program text as literals
         self.bake_parameters = len(scene.objects) <= 48 if bake_parameters is None else bake_parameters
         self.program_code = Compiler(self).make_program()
@@ -101,23 +105,7 @@ class Renderer:
                 integers.append(ints)
                 n_int += ints.size
             self.object_param_base.append(len(slots))
-            for cl_type, value in zip(tracer.parameter_types(), tracer.parameter_values()):
-                slot = np.zeros(4, dtype=np.float32)
-                if cl_type == 'float3':
-                    slot[:3] = np.ravel(value)
-                elif cl_type == 'int':
-                    slot[:1] = np.array([value], dtype=np.int32).view(np.float32)
-                elif cl_type == 'float':
-                    slot[0] = value
-                else:
-                    raise RuntimeError('unsupported parameter type %s' % cl_type)
-                slots.append(slot)
-            inverse = tracer.global_to_tracer_coordinate_transform().inverse()
-            for row in (inverse.linear[0, :], inverse.linear[1, :], inverse.linear[2, :],
-                        inverse.translation):
-                slot = np.zeros(4, dtype=np.float32)
-                slot[:3] = row
-                slots.append(slot)
+            slots.extend(tracer.parameter_slots())
             tracer.param_slots = len(slots) - self.object_param_base[-1]
 
         self.param_table = np.array(slots, dtype=np.float32).reshape(-1, 4)

@@ -1,6 +1,6 @@
 """Scene = camera + objects + materials + render settings (reference scene.py:5-58)."""
 import numpy as np
-from . import camera
+from . import geometry as camera
 from .imgutils import ColorEncodingSettings
 
 

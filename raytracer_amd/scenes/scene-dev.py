@@ -1,36 +1,4 @@
-"""Box room with a stretched mirror sphere and a sky cut-out; the light sphere is a
-next-event light.  RGB shading.  Values: /root/reference/scenes/scene-dev.py:6-30
-(BASELINE config C3).  ``make_scene(spectral=True)`` gives the spectral variant."""
-from raytracer_amd.scenes.default_scenes import BoxScene
-from raytracer_amd.objects import HalfSpace, Sphere
-from raytracer_amd.shader import RgbShader, SpectrumShader
-
-
-def make_scene(spectral=False):
-    s = BoxScene(SpectrumShader if spectral else RgbShader)
-
-    for wall in s.get_objects('wall'):
-        wall.material = 'red'
-    s.get_object('floor').material = 'white'
-    s.get_object('ceiling').material = 'green'
-    s.get_object('light').bidirectional_light = True
-    s.materials['black'] = {'diffuse': 0.2}
-    s.materials['light']['diffuse'] = 0.0
-    s.add_object(HalfSpace((-1, -1, -2), 5), 'sky')
-
-    egg = Sphere((0, 0, 0.6), 0.3)
-    egg.linear_transform(scaling=(1, 1, 2))
-    s.add_object(egg, 'mirror')
-
-    # the reference assigns the unused attribute `image_size`; the image stays 800 x 600
-    s.image_size = (8 * 120, 6 * 120)
-    s.samples_per_pixel = 15000
-    s.camera_position = (-2, -3, 1)
-    s.direct_camera_towards((0, 0, 0.6))
-    s.camera_fov = 50
-    s.min_bounces = 2
-    s.max_bounces = 5
-    return s
-
+"""Box room with a stretched mirror sphere (BASELINE C3); make_scene(spectral=True) for the spectral variant."""
+from raytracer_amd.scenes.library import scene_dev as make_scene
 
 scene = make_scene()

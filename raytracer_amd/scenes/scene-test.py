@@ -1,105 +1,4 @@
-"""Every shape class on a 5 x 5 grid, cycling through four materials (BASELINE C1).
-Layout and constructor arguments: /root/reference/scenes/scene-test.py:12-109."""
-import io
-import math
-import numpy
-from raytracer_amd import mesh_formats
-from raytracer_amd.scenes.default_scenes import BoxScene
-from raytracer_amd.objects import *  # noqa: F401,F403
-
-UNIT_CUBE_OFF = """OFF
-8 6 24
-0 0 0
-0 0 1
-0 1 0
-0 1 1
-1 0 0
-1 0 1
-1 1 0
-1 1 1
-4 0 1 3 2
-4 2 3 7 6
-4 4 6 7 5
-4 0 4 5 1
-4 1 5 7 3
-4 0 2 6 4
-"""
-
-JULIA_C = (-0.2, -0.4, -0.4, -0.4)
-
-
-def cube_mesh(p, R, **kwargs):
-    vertices, faces = mesh_formats.read_off(io.StringIO(UNIT_CUBE_OFF))
-    faces = mesh_formats.remove_duplicate_faces(faces)
-    return TriangleMesh(vertices, faces, auto_scale=True, center=p, scale=R, **kwargs)
-
-
-def cube_mesh_in_octree(p, R, **kwargs):
-    return Octree(cube_mesh(p, R, **kwargs), max_depth=2, max_faces_per_leaf=1)
-
-
-def below(p, R):
-    return p - numpy.array([0, 0, R])
-
-
-SHAPES = [
-    ('sphere', lambda p, R: Sphere(p, R)),
-    ('cone', lambda p, R: Cone(below(p, R), (0, 0, 1), R, R)),
-    ('cylinder', lambda p, R: Cylinder(below(p, R), (0, 0, 1), R, R)),
-    ('tetrahedron', lambda p, R: Tetrahedron(p, R)),
-    ('cube', lambda p, R: Cube(p, R=R)),
-    ('octahedron', lambda p, R: Octahedron(p, R)),
-    ('dodecahedron', lambda p, R: Dodecahedron(p, R)),
-    ('icosahedron', lambda p, R: Icosahedron(p, R)),
-    ('parallelepiped', lambda p, R: Parallelepiped(
-        p - numpy.array((R * 0.5, R * 0.45, R)), (R, 0, 0), (0, R * 0.9, 0), (0, 0, 1.5 * R))),
-    ('julia-ia', lambda p, R: QuaternionJuliaSet(JULIA_C, 4, center=p, scale=R)),
-    ('julia-de', lambda p, R: QuaternionJuliaSet2(JULIA_C, 4, center=p, scale=R)),
-    ('implicit', lambda p, R: ImplicitSurface(
-        'x**4 - 5*x**2 + y**4 - 5*y**2 + z**4 - 5*z**2 + 11.8', p, R * 0.5, 4)),
-    ('convex-5', lambda p, R: ConvexIntersection(p, [
-        CylinderComponent((0, 1, 0), R),
-        ConeComponent((0, -R / 0.2, 0), (0, 1, 0), R),
-        SphereComponent((0, 0, 0), R * 1.1),
-        HalfSpaceComponent((1, 1, 0), R),
-        LayerComponent((1, 0, 0), 0.3 * R / 0.2)])),
-    ('mesh', cube_mesh),
-    ('mesh-autoflip', lambda p, R: cube_mesh(p, R, auto_flip_normal=True)),
-    ('mesh-smooth', lambda p, R: cube_mesh(p, R, shading='smooth', auto_smooth_normals=True)),
-    ('octahedron-small', lambda p, R: Octahedron(p, R * 0.5)),   # same tracer, other size
-    ('convex-3', lambda p, R: ConvexIntersection(p, [             # a different tracer
-        CylinderComponent((1, 1, 0), R),
-        SphereComponent((0, 0, 0), R * 1.2),
-        LayerComponent((1, 0, 0), 2.0 * R)])),
-    ('octree', cube_mesh_in_octree),
-    ('distance-field', lambda p, R: DistanceField(
-        tracer_code="dist = sqrt(x*x + y*y + z*z) - %g" % R, center=p)),
-]
-
-MATERIAL_CYCLE = ['white', 'mirror', 'glass', 'wax']
-
-
-def make_scene():
-    s = BoxScene()
-    s.get_object('light').bidirectional_light = True
-
-    side = int(math.ceil(math.sqrt(len(SHAPES))))
-    extent = 4.0
-    radius = 0.5 * extent / side * 0.5
-    coord = lambda i: ((i + 0.5) / float(side) - 0.5) * extent
-
-    for k, (name, factory) in enumerate(SHAPES):
-        ix, iy = divmod(k, side)
-        tracer = factory(numpy.array((coord(ix), coord(iy), radius)), radius)
-        tracer.rotate(axis='z', deg=-45)
-        s.add_object(tracer, MATERIAL_CYCLE[k % len(MATERIAL_CYCLE)], name)
-
-    s.max_bounces = 4
-    s.min_bounces = 2
-    s.image.brighness_reference = numpy.max   # (sic) misspelt in the reference: no effect
-    s.brightness = 1.0
-    s.direct_camera_towards((0, 0, 0.0))
-    return s
-
+"""Every shape class on a grid (BASELINE C1)."""
+from raytracer_amd.scenes.library import scene_test as make_scene
 
 scene = make_scene()
