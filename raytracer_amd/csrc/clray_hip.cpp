@@ -165,12 +165,10 @@ int clr_program_build(clr_ctx *ctx, const char *source, int n_options, const cha
         delete prog;
         return rc;
     }
-    if (check(hipModuleGetFunction(&prog->render, prog->module, "clr_render"), "clr_render") ||
-        check(hipModuleGetFunction(&prog->first_hit, prog->module, "clr_first_hit"), "clr_first_hit")) {
-        (void)hipModuleUnload(prog->module);
-        delete prog;
-        return 1;
-    }
+    // a program for clr_launch only (unit kernels) need not hold the two fixed entry kernels
+    if (hipModuleGetFunction(&prog->render, prog->module, "clr_render") != hipSuccess) prog->render = nullptr;
+    if (hipModuleGetFunction(&prog->first_hit, prog->module, "clr_first_hit") != hipSuccess) prog->first_hit = nullptr;
+    (void)hipGetLastError();
     *out = prog;
     return 0;
 }
@@ -242,6 +240,7 @@ int clr_launch(clr_program *prog, const char *kernel, const unsigned grid[3],
 int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms) {
     if (!prog || !a) return fail("null argument");
     if (int rc = set_device(prog->ctx)) return rc;
+    if (!prog->render) return fail("clr_render_passes: the program has no kernel clr_render");
     if (a->n_pixels <= 0 || a->n_passes < 0) return fail("clr_render_passes: bad n_pixels / n_passes");
     if (!a->img || !a->cam || !a->pass_tape || !a->bounce_tape)
         return fail("clr_render_passes: img, cam, pass_tape and bounce_tape are required");
@@ -264,6 +263,7 @@ int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape, con
                   void *out_normal, void *stream) {
     if (!prog) return fail("null argument");
     if (int rc = set_device(prog->ctx)) return rc;
+    if (!prog->first_hit) return fail("clr_first_hit: the program has no kernel clr_first_hit");
     if (n_pixels <= 0 || !cam || !pass_tape || !out_ids || !out_t || !out_normal)
         return fail("clr_first_hit: bad arguments");
     void *args[] = {&cam, &pass_tape, &vector_data, &integer_data, &n_pixels, &out_ids, &out_t, &out_normal};

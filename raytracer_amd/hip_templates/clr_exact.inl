@@ -1,0 +1,137 @@
+// Correctly rounded binary32 division and square root in fewer instructions than the
+// compiler's generic expansions, by speculation.  Device code only.  The values returned are
+// the IEEE-754 round-to-nearest results, bit for bit what `a / b` and `sqrtf(x)` give (and
+// what the CPU oracle computes); tests/test_gpu_exact_math.py checks that on 2^30 operand
+// tuples per exponent range.
+//
+// Division.  The generic expansion is v_div_scale x2, v_rcp, a Newton step on the reciprocal,
+// quotient + two residual corrections, v_div_fmas, v_div_fixup.  The two scale steps and the
+// fix-up are the identity when
+//     both operands are finite and non-zero,  |a| >= 2^-103,  |d| normal and < 2^126,
+//     exponent(a) - exponent(d) < 96  and the quotient is not denormal,
+// all of which hold for 2^-47 <= |a|, |d| <= 2^47.  What remains is the FMA chain below: its
+// first half depends on the divisor only and is shared by all quotients with that divisor
+// (ray / |ray| and t / |ray| of every object test), and two quotients at a time go through
+// packed FP32 instructions.
+// Square root.  v_sqrt_f32 is within 1 ulp; its two neighbours are tested with one FMA residual
+// each, as in the generic expansion, whose input scaling, un-scaling and class test matter only
+// below 2^-96.
+//
+// Speculation.  The short sequences carry no range tests.  Instead the operands are folded into
+// two running bounds (clr_guard_spec) and the caller checks the bounds once per path segment: if
+// they left the range the segment is computed again from its saved state with the generic
+// arithmetic (clr_guard_safe).  Generated functions are templates over the guard type, so both
+// versions come from one source text.  The bounds are kept on the bit patterns with integer
+// min / max (the operands tracked are non-negative: squares, lengths, distances, discriminants;
+// a negative one or a NaN lands outside the range):
+//     lo = smallest of  x^2, y^2, z^2 of every direction,  every t,  every sqrt argument
+//     hi = largest of   every length, every t, every square root
+// and the range is lo >= 2^-94, hi <= 2^30.  Then components are >= 2^-47 and lengths are in
+// [2^-47, 2^30], so quotients component / length and t / length are normal numbers with an
+// exponent difference < 96 and numerators >= 2^-103, and sqrt arguments are in [2^-94, 2^60].
+typedef float clr_f2 __attribute__((ext_vector_type(2)));
+
+#ifndef CLR_GUARD_LO
+#define CLR_GUARD_LO 0x1p-94f
+#endif
+#ifndef CLR_GUARD_HI
+#define CLR_GUARD_HI 0x1p+30f
+#endif
+
+struct clr_guard_safe {};                // generic arithmetic, nothing to track
+struct clr_guard_spec { int lo, hi; };   // short sequences; bit patterns of the bounds
+
+#define CLR_BITS(v) __float_as_int(v)
+#define CLR_IMIN(a, b) ((a) < (b) ? (a) : (b))
+#define CLR_IMAX(a, b) ((a) > (b) ? (a) : (b))
+
+CLR_FN void clr_guard_reset(const clr_guard_safe &) {}
+CLR_FN bool clr_guard_ok(const clr_guard_safe &) { return true; }
+CLR_FN void clr_guard_reset(clr_guard_spec &g) { g.lo = CLR_BITS(1.0f); g.hi = CLR_BITS(1.0f); }
+CLR_FN bool clr_guard_ok(const clr_guard_spec &g) {
+    return g.lo >= CLR_BITS(CLR_GUARD_LO) && g.hi <= CLR_BITS(CLR_GUARD_HI);
+}
+
+// ---- the short sequences (valid inside the range only)
+CLR_FN float clr_sqrt_short(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __int_as_float(__float_as_int(s) - 1);
+    const float up = __int_as_float(__float_as_int(s) + 1);
+    const float r_down = __builtin_fmaf(-down, s, x);
+    const float r_up = __builtin_fmaf(-up, s, x);
+    s = r_down <= 0.0f ? down : s;
+    s = r_up > 0.0f ? up : s;
+    return s;
+}
+
+CLR_FN float clr_reciprocal_short(float d) {
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+
+CLR_FN float clr_quotient_short(float a, float d, float y) {
+    float q = a * y;
+    float r = __builtin_fmaf(-d, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-d, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+CLR_FN clr_f2 clr_quotient_short(clr_f2 a, float d, float y) {
+    const clr_f2 dd = {-d, -d}, yy = {y, y};
+    clr_f2 q = a * yy;
+    clr_f2 r = __builtin_elementwise_fma(dd, q, a);
+    q = __builtin_elementwise_fma(r, yy, q);
+    r = __builtin_elementwise_fma(dd, q, a);
+    return __builtin_elementwise_fma(r, yy, q);
+}
+
+// ---- square root
+CLR_FN float clr_sqrt(float x, const clr_guard_safe &) { return sqrtf(x); }
+CLR_FN float clr_sqrt(float x, clr_guard_spec &g) {
+    const float s = clr_sqrt_short(x);
+    g.lo = CLR_IMIN(g.lo, CLR_BITS(x));
+    g.hi = CLR_IMAX(g.hi, CLR_BITS(s));
+    return s;
+}
+
+// ---- a vector, its length and the quotients by that length
+struct clr_direction {
+    vec3 unit;     // v / |v|
+    float len;     // |v|
+    float y;       // reciprocal of len after the Newton step (speculative version only)
+};
+
+CLR_FN clr_direction clr_make_direction(vec3 v, const clr_guard_safe &) {
+    clr_direction r;
+    r.len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    r.unit = make_vec3(v.x / r.len, v.y / r.len, v.z / r.len);
+    r.y = 0.0f;
+    return r;
+}
+
+CLR_FN clr_direction clr_make_direction(vec3 v, clr_guard_spec &g) {
+    clr_direction r;
+    const float xx = v.x * v.x, yy = v.y * v.y, zz = v.z * v.z;
+    r.len = clr_sqrt_short(xx + yy + zz);
+    r.y = clr_reciprocal_short(r.len);
+    const clr_f2 xy = clr_quotient_short((clr_f2){v.x, v.y}, r.len, r.y);
+    r.unit = make_vec3(xy.x, xy.y, clr_quotient_short(v.z, r.len, r.y));
+    g.lo = CLR_IMIN(CLR_IMIN(g.lo, CLR_BITS(xx)), CLR_BITS(yy));
+    g.lo = CLR_IMIN(g.lo, CLR_BITS(zz));
+    return r;
+}
+
+// upper bound of a direction's length and of a distance along it (t <= 0: no hit, not divided)
+CLR_FN void clr_guard_upper(const clr_direction &, float, const clr_guard_safe &) {}
+CLR_FN void clr_guard_upper(const clr_direction &dir, float t, clr_guard_spec &g) {
+    g.hi = CLR_IMAX(CLR_IMAX(g.hi, CLR_BITS(dir.len)), CLR_BITS(t));
+}
+
+// t / dir.len for t > 0, after clr_guard_upper(dir, t, g)
+CLR_FN float clr_over_length(float t, const clr_direction &dir, const clr_guard_safe &) { return t / dir.len; }
+CLR_FN float clr_over_length(float t, const clr_direction &dir, clr_guard_spec &g) {
+    g.lo = CLR_IMIN(g.lo, CLR_BITS(t));
+    return clr_quotient_short(t, dir.len, dir.y);
+}

@@ -46,16 +46,18 @@ __constant__ float clr_material_scalars[{{ 5*(n_objects+1) }}];
 #define CLR_MATERIAL_ROW {{ 10*(n_objects+1) }}
 
 // closest hit over every object of the scene (renderer.py:338-344)
+template<class CLR_G>
 CLR_FN void clr_closest_hit(const vec3 pos, const vec3 ray, float &isec_dist, uint &whichobject,
     uint &which_subobject, const uint last_whichobject, const uint last_which_subobject,
-    const uint inside, const float4 * __restrict__ vector_data, const int * __restrict__ integer_data)
+    const uint inside, const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
+    CLR_G &clr_g)
 {
 ### for tracer, count, offset in renderer.object_groups
     #pragma unroll {{ count if renderer.bake_parameters else [count, 8]|min }}
     for (int i = 0; i < {{ count }}; ++i)
         {{ tracer.tracer_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject,
             last_whichobject, last_which_subobject, inside, vector_data, integer_data,
-            {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[loop.index0] }} + i*{{ renderer.group_param_stride[loop.index0] }});
+            {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[loop.index0] }} + i*{{ renderer.group_param_stride[loop.index0] }}, clr_g);
 ### endfor
 }
 
@@ -74,16 +76,19 @@ CLR_FN vec3 clr_surface_normal(const vec3 pos, const vec3 ray, const uint whicho
 
 ### if renderer.bidirectional
 // visibility of the light point from the hit point (renderer.py:373-382, tracer.cl:143-221)
+template<class CLR_G>
 CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint whichobject,
     const uint which_subobject, const uint inside, const int diffusions_left,
     const vec3 dest, const int light_id,
-    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data)
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g)
 {
     if (diffusions_left < 1) return 0.0f;
-    vec3 ray = dest - pos;
-    if (dot(normal, ray) < 0.0f) return 0.0f;
-    const float isec_dist = length(ray);
-    ray = ray / isec_dist;
+    const vec3 to_light = dest - pos;
+    if (dot(normal, to_light) < 0.0f) return 0.0f;
+    const clr_direction light_dir = clr_make_direction(to_light, clr_g);
+    clr_guard_upper(light_dir, 0.0f, clr_g);
+    const float isec_dist = light_dir.len;
+    const vec3 ray = light_dir.unit;
     float shadow_mask = 1.0f;
 ### for tracer, count, offset in renderer.object_groups
     #pragma unroll {{ count if renderer.bake_parameters else [count, 8]|min }}
@@ -91,7 +96,7 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
         if ({{ offset+1 }} + i != light_id)
             {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,
                 shadow_mask, vector_data, integer_data,
-                {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[loop.index0] }} + i*{{ renderer.group_param_stride[loop.index0] }});
+                {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[loop.index0] }} + i*{{ renderer.group_param_stride[loop.index0] }}, clr_g);
 ### endfor
     return shadow_mask;
 }
@@ -128,17 +133,19 @@ CLR_FN void clr_start_path(PathState &s, const float4 * __restrict__ rec, const 
 #define CLR_DBG_STRIDE 6   // float4 records per (segment, pixel) in the debug dump
 
 // One path segment: closest hit, normal, light visibility, shading, roulette
-// (renderer.py:326-433).  Returns false when the path ends.
+// (renderer.py:326-433).  Returns false when the path ends.  clr_g selects the arithmetic of
+// the two object sweeps: speculative short sequences or the generic ones (clr_exact.inl).
+template<class CLR_G>
 CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last, const vec3 cmask,
     vec3 &img, const float * __restrict__ material_row,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-    float4 * __restrict__ dbg)
+    float4 * __restrict__ dbg, CLR_G &clr_g)
 {
     float isec_dist = CLR_MAX_RAY_LENGTH;
     const uint last_whichobject = s.whichobject, last_which_subobject = s.which_subobject;
     uint whichobject = 0, which_subobject = last_which_subobject;
     clr_closest_hit(s.pos, s.ray, isec_dist, whichobject, which_subobject,
-                    last_whichobject, last_which_subobject, s.inside, vector_data, integer_data);
+                    last_whichobject, last_which_subobject, s.inside, vector_data, integer_data, clr_g);
     if (whichobject == 0) {
         // open scene: the reference leaves this case undefined; end the path
         if (dbg) { dbg[0] = make_float4(0.0f, 0.0f, __int_as_float((int)s.inside), __int_as_float(s.diffusions_left));
@@ -154,7 +161,7 @@ CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last,
 ### if renderer.bidirectional
     if (!is_last)
         shadow_mask = clr_light_visibility(s.pos, normal, whichobject, which_subobject, s.inside,
-            s.diffusions_left, B.light_point, B.light_id, vector_data, integer_data);
+            s.diffusions_left, B.light_point, B.light_id, vector_data, integer_data, clr_g);
 ### endif
     const bool alive = clr_shade(s, normal, isec_dist, shadow_mask, B, is_last, cmask, img
 ### if not shader.rgb
@@ -174,6 +181,16 @@ CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last,
     }
     return alive;
 }
+
+### if renderer.speculate
+// the replay of a segment with the generic arithmetic: rare, kept out of the render loop
+static __device__ __attribute__((noinline)) bool clr_segment_generic(PathState *s, const BounceSample *B,
+    const bool is_last, const vec3 cmask, vec3 *img, const float * __restrict__ material_row,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, float4 * __restrict__ dbg)
+{
+    return clr_segment(*s, *B, is_last, cmask, *img, material_row, vector_data, integer_data, dbg, clr_g);
+}
+### endif
 
 // ---------------------------------------------------------------------------------------
 // Render kernel.  Lane k owns pixel k (blocked pixel order) and accumulates its radiance in
@@ -204,6 +221,10 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
     int segment = 0;
     bool active = false;
     vec3 cmask = make_vec3(1.0f, 1.0f, 1.0f);
+### if renderer.speculate
+    vec3 acc_at_pass_start = acc;
+    bool generic_path = false;
+### endif
 
     for (;;) {
         const bool wave_busy = __any(active);
@@ -213,14 +234,46 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
             cmask = make_vec3(rec[5]);
             segment = 0;
             active = true;
+### if renderer.speculate
+            acc_at_pass_start = acc;
+            generic_path = false;
+### endif
         }
         if (!__any(active)) break;
         if (active) {
             const BounceSample B = clr_load_bounce(bounce_tape + ((size_t)pass * CLR_MAX_BOUNCES + segment) * CLR_BOUNCE_STRIDE);
             const bool is_last = segment == CLR_MAX_BOUNCES - 1;
             float4 *d = dbg ? dbg + ((size_t)segment * n_pixels + k) * CLR_DBG_STRIDE : nullptr;
-            const bool alive = clr_segment(s, B, is_last, cmask, acc,
-                material_rows + (size_t)pass * CLR_MATERIAL_ROW, vector_data, integer_data, d);
+            const float *material_row = material_rows + (size_t)pass * CLR_MATERIAL_ROW;
+### if renderer.speculate
+            // Speculative arithmetic first.  If an operand leaves the range in which it is exact,
+            // the lane takes the radiance it had at the start of the pass, starts the path of
+            // this pass again and walks it with the generic arithmetic (rare; out of line).
+            bool alive;
+            if (!generic_path) {
+                clr_guard_spec spec;
+                clr_guard_reset(spec);
+                alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, spec);
+                if (!clr_guard_ok(spec)) {
+                    acc = acc_at_pass_start;
+                    clr_start_path(s, pass_tape + (size_t)pass * CLR_PASS_STRIDE, base_ray);
+                    segment = 0;
+                    generic_path = true;
+                    continue;
+                }
+            }
+            else {
+                // only copies of the state escape to the callee
+                PathState s1 = s;
+                vec3 acc1 = acc;
+                BounceSample B1 = B;
+                alive = clr_segment_generic(&s1, &B1, is_last, cmask, &acc1, material_row, vector_data, integer_data, d);
+                s = s1;
+                acc = acc1;
+            }
+### else
+            const bool alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, clr_g);
+### endif
             segment++;
             if (!alive) { active = false; pass++; }
         }
@@ -242,7 +295,7 @@ clr_first_hit(const float4 * __restrict__ cam, const float4 * __restrict__ pass_
     float isec_dist = CLR_MAX_RAY_LENGTH;
     uint whichobject = 0, which_subobject = 0;
     clr_closest_hit(s.pos, s.ray, isec_dist, whichobject, which_subobject, 0, 0, s.inside,
-                    vector_data, integer_data);
+                    vector_data, integer_data, clr_g);
     vec3 normal = make_vec3(0.0f, 0.0f, 0.0f);
     if (whichobject != 0)
         normal = clr_surface_normal(s.pos + isec_dist * s.ray, s.ray, whichobject, which_subobject,

@@ -25,7 +25,7 @@
                 c_face = prev_face - {{ first }};
 
             {{ component.tracer_function_name }}(
-                {{ obj.component_tracer_call_params(idx) }}
+                {{ obj.component_tracer_call_params(idx) }}, clr_g
             );
 
             if (c_enter > lo) {

@@ -51,7 +51,14 @@ CLR_FN float length(vec3 a) { return sqrtf(dot(a, a)); }
 CLR_FN float length(vec4 a) { return sqrtf(dot(a, a)); }
 CLR_FN vec3 normalize(vec3 a) { return a / length(a); }
 #define fast_normalize normalize
-#define native_sqrt sqrtf
+
+// ---- exact division / square root with operand-range speculation (see clr_exact.inl).
+// Generated shape functions and per-class steps are templates over a guard type and receive the
+// guard as their last argument `clr_g`; code outside such a function finds this global, stateless
+// guard under the same name and gets the generic arithmetic.
+{% include 'clr_exact.inl' %}
+static __device__ const clr_guard_safe clr_g = {};
+#define native_sqrt(x) clr_sqrt((x), clr_g)
 
 #define CLR_MATH_FN CLR_FN
 {% include 'clr_math.inl' %}

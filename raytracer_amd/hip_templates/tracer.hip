@@ -17,7 +17,7 @@ CLR_FN void {{ obj.normal_function_name }}(
 
 ### macro tracer_function_base(obj)
 {#- distance to the nearest valid intersection of a ray with the shape, tracer coordinates #}
-CLR_FN void {{ obj.tracer_function_name }}(
+template<class CLR_G> CLR_FN void {{ obj.tracer_function_name }}(
         const vec3 origin,
         const vec3 ray,
         const float t_limit,   // upper bound for the distance
@@ -25,20 +25,22 @@ CLR_FN void {{ obj.tracer_function_name }}(
         uint *p_subobject,           // [in/out] e.g. which face
         bool inside,                 // ray travels inside this object
         bool on_surface             // ray starts on this object's surface
-        {{ obj.parameter_declaration_string() }}) {
+        {{ obj.parameter_declaration_string() }},
+        CLR_G &clr_g) {              // operand-range guard of native_sqrt (clr_exact.inl)
 {{ caller() }}
 }
 ### endmacro
 
 ### macro tracer_component_function_base(obj)
-CLR_FN void {{ obj.tracer_function_name }}(
+template<class CLR_G> CLR_FN void {{ obj.tracer_function_name }}(
         const vec3 origin,
         const vec3 ray,
         float *t_enter,         // [in/out] interval of the ray inside the component
         float *t_exit,
         uint *p_subobject,
         bool inside
-        {{ obj.parameter_declaration_string() }}) {
+        {{ obj.parameter_declaration_string() }},
+        CLR_G &clr_g) {
 {{ caller() }}
 }
 ### endmacro
@@ -62,11 +64,11 @@ CLR_FN void {{ obj.tracer_function_name }}(
 
 ### macro tracer_kernel(obj)
 // closest-hit step for one object of this class (tracer.cl:72-141)
-CLR_FN void {{ obj.tracer_kernel_name }}(
+template<class CLR_G> CLR_FN void {{ obj.tracer_kernel_name }}(
     const vec3 pos, const vec3 ray, float &isec_dist, uint &whichobject, uint &which_subobject,
     const uint last_whichobject, const uint last_which_subobject, const uint inside,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-    const int object_id, const float4 *P)
+    const int object_id, const float4 *P, CLR_G &clr_g)
 {
     const bool within = inside == (uint)object_id,
                on_surface = last_whichobject == (uint)object_id;
@@ -79,16 +81,19 @@ CLR_FN void {{ obj.tracer_kernel_name }}(
 
         const vec3 local_pos = apply_affine_transform(p_inverse_affine, pos);
         const vec3 local_ray = apply_linear_transform(p_inverse_affine, ray);
-        const float stretch = length(local_ray);
+        // unit direction, stretch = |local_ray|; the four quotients by stretch share one reciprocal
+        const clr_direction dir = clr_make_direction(local_ray, clr_g);
 
         {{ obj.tracer_function_name }}(
-            local_pos, local_ray/stretch, isec_dist*stretch, &new_isec_dist, &cur_subobject,
+            local_pos, dir.unit, isec_dist*dir.len, &new_isec_dist, &cur_subobject,
             within, on_surface
             {{ tracer_params(obj) }}
+            , clr_g
         );
 
+        clr_guard_upper(dir, new_isec_dist, clr_g);
         if (new_isec_dist > 0) {
-            new_isec_dist /= stretch;
+            new_isec_dist = clr_over_length(new_isec_dist, dir, clr_g);
             if (new_isec_dist < isec_dist) {
                 isec_dist = new_isec_dist;
                 which_subobject = cur_subobject;
@@ -104,11 +109,11 @@ CLR_FN void {{ obj.tracer_kernel_name }}(
 ### macro shadow_kernel(obj)
 // visibility step towards the light point for one object of this class (tracer.cl:143-221);
 // `ray`/`isec_dist` = unit direction and distance to the light point, computed by the caller
-CLR_FN void {{ obj.shadow_kernel_name }}(
+template<class CLR_G> CLR_FN void {{ obj.shadow_kernel_name }}(
     const vec3 pos, const vec3 ray, const float isec_dist,
     const uint whichobject, const uint which_subobject, const uint inside, float &shadow_mask,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-    const int object_id, const float4 *P)
+    const int object_id, const float4 *P, CLR_G &clr_g)
 {
     uint subobject = which_subobject;
     const bool within = inside == (uint)object_id,
@@ -120,16 +125,19 @@ CLR_FN void {{ obj.shadow_kernel_name }}(
         const float4 *p_inverse_affine = P + {{ obj.parameter_types()|length }};
         const vec3 local_pos = apply_affine_transform(p_inverse_affine, pos);
         const vec3 local_ray = apply_linear_transform(p_inverse_affine, ray);
-        const float stretch = length(local_ray);
+        // unit direction, stretch = |local_ray|; the four quotients by stretch share one reciprocal
+        const clr_direction dir = clr_make_direction(local_ray, clr_g);
 
         {{ obj.tracer_function_name }}(
-            local_pos, local_ray/stretch, isec_dist*stretch, &new_isec_dist, &subobject,
+            local_pos, dir.unit, isec_dist*dir.len, &new_isec_dist, &subobject,
             within, on_surface
             {{ tracer_params(obj) }}
+            , clr_g
         );
 
+        clr_guard_upper(dir, new_isec_dist, clr_g);
         if (new_isec_dist > 0) {
-            new_isec_dist /= stretch;
+            new_isec_dist = clr_over_length(new_isec_dist, dir, clr_g);
             if (new_isec_dist < isec_dist) shadow_mask = 0.0f;
         }
     ### if obj.convex

@@ -59,6 +59,10 @@ def pack_slot(type_name, value):
 class Tracer(object):
     """A three-dimensional body with a ray-intersection and a normal function."""
 
+    # True for shapes whose ray test is a few divisions / square roots: the renderer then uses
+    # the speculative exact arithmetic of hip_templates/clr_exact.inl for the scene
+    speculation_friendly = False
+
     def __init__(self, position=(0, 0, 0), **affine_kwargs):
         # non-empty => one generated function per instance instead of one per class
         self.unique_tracer_id = ""

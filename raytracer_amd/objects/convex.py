@@ -25,6 +25,7 @@ def vec_literal(vec):
 
 class ConvexIntersection(Tracer):
     """Intersection of convex bodies; run-time parameters, one function per component list."""
+    speculation_friendly = True
 
     class Component(Tracer):
         def __init__(self, pos=(0, 0, 0)):

@@ -7,6 +7,7 @@ from ..geometry import Affine, rotation_aligning_vectors
 
 
 class Sphere(Tracer):
+    speculation_friendly = True
 
     def __init__(self, pos, R):
         Tracer.__init__(self, position=pos)
@@ -42,6 +43,7 @@ class Sphere(Tracer):
 
 class HalfSpace(Tracer):
     """{x : normal.x <= h}; in tracer coordinates the boundary is the plane x = 0."""
+    speculation_friendly = True
 
     def __init__(self, normal, h):
         Tracer.__init__(self)

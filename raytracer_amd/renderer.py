@@ -27,7 +27,7 @@ class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
-                 min_waves_per_simd=None):
+                 min_waves_per_simd=None, speculate=None):
         self.scene = scene
         # tile partitioning: (first ray, count) in ray order; a contiguous range of ray
         # indices is a set of 4-pixel-wide column blocks of the frame (get_image_order)
@@ -42,6 +42,15 @@ class Renderer:
         self._init_camera_and_image()
         self._init_materials()
 
+        # exact division / square root by operand-range speculation with per-segment replay
+        # (hip_templates/clr_exact.inl); False = the compiler's generic expansions everywhere
+        # default: on when every shape of the scene is a quadric / convex body - their steps are
+        # dominated by the divisions and square roots of the ray set-up.  Marching and mesh
+        # shapes gain nothing and their kernels are register-bound: the second copy of the
+        # segment code costs them a wave of occupancy (scene-test: 239 -> 262 VGPRs).
+        if speculate is None:
+            speculate = all(getattr(obj.tracer, 'speculation_friendly', False) for obj in scene.objects)
+        self.speculate = speculate
         # optional occupancy hint for the render kernel (second __launch_bounds__ argument)
         self.min_waves_per_simd = min_waves_per_simd
         # small scenes: bake the per-object parameters into the program text as literals

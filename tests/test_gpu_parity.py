@@ -308,3 +308,32 @@ def test_generic_launch_and_buffer_helpers():
     assert (host[:16] == 7.0).all() and np.array_equal(host[16:], t_ref[16:])
     with pytest.raises(Exception):
         acc.call('no_such_kernel', 1, ())
+
+
+@pytest.mark.parametrize('name,options', [
+    ('scene-dev', []),
+    ('scene-three-objects', []),
+    ('scene-test', []),                               # off by default for this scene: forced on here
+    ('scene-dev', ['-DCLR_GUARD_LO=0x1p-7f']),        # most paths restart with the generic arithmetic
+    ('scene-three-objects', ['-DCLR_GUARD_LO=0x1p-7f', '-DCLR_GUARD_HI=0x1p+2f']),
+])
+@pytest.mark.parametrize('regenerate', [False, True])
+def test_speculative_arithmetic_and_path_restart_are_exact(name, options, regenerate):
+    """The short division / square-root sequences with operand-range speculation
+    (hip_templates/clr_exact.inl) give the oracle's bits, both when no path restarts and when
+    a tightened range makes most of them restart."""
+    from oracle import oracle
+    from raytracer_amd.hip_compiler import PARITY_OPTIONS
+    r = Renderer(load_scene(name, (64, 48)), seed=5, speculate=True, build_options=PARITY_OPTIONS + options)
+    assert 'clr_segment_generic' in r.program_code
+    r.regenerate = regenerate
+    osc = oracle.OracleScene(r)
+    tape = r.make_tape(0, 1)
+    _, dump = r.render_tape(tape, debug=True)
+    oimg, odump, _ = osc.render(tape, debug=True)
+    assert np.array_equal(bits(dump), bits(odump))
+    assert np.array_equal(bits(r.img.get()), bits(oimg))
+    tape = r.make_tape(1, 9)
+    r.render_tape(tape)
+    oimg, _, _ = osc.render(tape, img=oimg)
+    assert np.array_equal(bits(r.img.get()), bits(oimg))

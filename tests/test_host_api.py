@@ -263,3 +263,9 @@ def test_reference_style_scene_file_imports_unchanged(tmp_path):
     scene = runpy.run_path(str(path))['scene']
     r = Renderer(scene, device=False, seed=0)
     assert len(r.scene.objects) == 9 and 'Cube_tracer' in r.program_code
+
+
+def test_speculation_is_off_for_marching_and_mesh_scenes():
+    assert Renderer(load_scene('scene-dev', (16, 8)), device=False).speculate
+    assert not Renderer(load_scene('scene-test', (16, 8)), device=False).speculate
+    assert 'clr_segment_generic' not in Renderer(load_scene('scene-marchers', (16, 8)), device=False).program_code

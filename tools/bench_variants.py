@@ -12,13 +12,29 @@ VARIANTS = {
     'fastmath': ['-O3', '-ffast-math', '-fno-hip-fp32-correctly-rounded-divide-sqrt'],
 }
 
+BASE = ['-O3', '-ffp-contract=off']
+SETS = {
+    'options': VARIANTS,
+    # exact division / square root: generic expansions vs operand-range speculation, and the
+    # speculation with a threshold that makes a large share of the segments replay
+    'exact': {
+        'parity': (BASE, {'speculate': False}),
+        'speculative': (BASE, {'speculate': True}),
+        'replay-heavy': (BASE + ['-DCLR_GUARD_LO=0x1p-7f'], {'speculate': True}),
+    },
+}
+
+
 def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
     rs = {}
     tape = None
     for name, opts in VARIANTS.items():
         scene = runpy.run_path('raytracer_amd/scenes/%s.py' % scene_name)['scene']
         scene.image.size = size
-        r = Renderer(scene, seed=0, build_options=opts)
+        kwargs = {}
+        if isinstance(opts, tuple):
+            opts, kwargs = opts
+        r = Renderer(scene, seed=0, build_options=opts, **kwargs)
         if tape is None:
             tape = r.make_tape(0, passes)
         r.upload_tape(tape)
@@ -45,4 +61,6 @@ def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
                  float(np.max(np.abs(t - t0) / np.abs(t0)))))
 
 if __name__ == '__main__':
+    if len(sys.argv) > 2:
+        VARIANTS = SETS[sys.argv[2]]
     main(*(sys.argv[1:2] or ['scene-dev']))
