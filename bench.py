@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument('--partition', choices=['passes', 'tiles'], default='passes',
                     help='passes: pass j on rank j mod N (weak scaling); tiles: every rank renders '
                          'all passes of its own slice of the frame (strong scaling)')
+    ap.add_argument('--occupancy-hint', default='auto',
+                    help="waves per SIMD the render kernel is compiled for: 'auto' (time the candidates "
+                         "before the run), 'none' or a number")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
@@ -123,6 +126,13 @@ def main():
                  build_options=args.build_options.split() if args.build_options else None,
                  bake_parameters=None if args.bake is None else bool(args.bake))
     r.regenerate = bool(args.regenerate)
+    if args.occupancy_hint == 'auto':
+        r.tune_occupancy()                      # part of the program build, outside the timed region
+        if rank == 0:
+            print('occupancy tuning (ms per hint):', {str(k): round(v, 3) for k, v in r.occupancy_timings.items()},
+                  file=sys.stderr)
+    elif args.occupancy_hint != 'none':
+        r.tune_occupancy(candidates=(int(args.occupancy_hint),))
     tiles = ray_range is not None
     frame = torch.zeros((width * height, 4), dtype=torch.float32, device='cuda')
     img = frame[ray_range[0]:ray_range[0] + ray_range[1]] if tiles else frame
@@ -172,6 +182,8 @@ def main():
                                'max_bounces %d), broadcast random tape, build options %s'
                                % (args.scene, width, height, P, scene.max_bounces, ' '.join(r.build_options)),
                    'passes_per_step': P, 'pixels': r.n_pixels,
+                   'speculative_exact_arithmetic': bool(r.speculate),
+                   'occupancy_hint': r.min_waves_per_simd,
                    'parallelism': ('%s x%d, one all-reduce' % ('tile-partitioned' if tiles else 'pass-striped', world))
                                   if world > 1 else 'single GPU'},
     }

@@ -57,6 +57,17 @@ int clr_program_set_global(clr_program *prog, const char *name, const void *host
 /* Compile only (no device needed): returns the code-object size; used by the build check. */
 int clr_compile_only(const char *source, int n_options, const char **options, const char *arch,
                      size_t *code_size);
+/* The two halves of clr_program_build, for callers that keep compiled programs (a disk cache)
+ * or compile in another process: compile for `arch` without a device (the binary is released
+ * with clr_binary_free), and load a code object made earlier.  The reference rebuilds its
+ * program from source on every start (accelerator.py:43-49; pyopencl keeps its own binary
+ * cache underneath). */
+int clr_compile(const char *source, int n_options, const char **options, const char *arch,
+                void **binary, size_t *size);
+void clr_binary_free(void *binary);
+int clr_program_load(clr_ctx *ctx, const void *binary, size_t size, clr_program **out);
+/* Version of the hiprtc that this process compiles with (part of a cache key). */
+int clr_compiler_version(int *major, int *minor);
 
 /* ---- buffers: replace to_device / new_array / new_const_buffer / enqueue_copy / Array.fill /
  * Array.get (accelerator.py:91-153, renderer.py:306-311) */

@@ -67,6 +67,10 @@ def load_library():
         'clr_program_destroy': (ci, [vp]),
         'clr_program_set_global': (ci, [vp, cp, vp, ctypes.c_size_t]),
         'clr_compile_only': (ci, [cp, ci, P(cp), cp, P(ctypes.c_size_t)]),
+        'clr_compile': (ci, [cp, ci, P(cp), cp, P(vp), P(ctypes.c_size_t)]),
+        'clr_binary_free': (None, [vp]),
+        'clr_program_load': (ci, [vp, vp, ctypes.c_size_t, P(vp)]),
+        'clr_compiler_version': (ci, [P(ci), P(ci)]),
         'clr_buffer_alloc': (ci, [vp, ctypes.c_size_t, P(vp)]),
         'clr_buffer_free': (ci, [vp, vp]),
         'clr_buffer_upload': (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
@@ -232,9 +236,12 @@ class Accelerator:
         if self.prog is not None:
             self.lib.clr_program_destroy(self.prog)
             self.prog = None
-        arr, n = _options_array(options)
+        # compile (system hiprtc, disk store: program_cache.py), then load the code object
+        from . import program_cache
+        arch = self.device_info()['arch'].split(':')[0]
+        binary, self.last_build = program_cache.get_binary(prog_code, list(options), arch)
         prog = ctypes.c_void_p()
-        _check(self.lib.clr_program_build(self.ctx, prog_code.encode('ascii'), n, arr, ctypes.byref(prog)))
+        _check(self.lib.clr_program_load(self.ctx, binary, len(binary), ctypes.byref(prog)))
         self.prog = prog
         return prog
 

@@ -7,6 +7,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -151,6 +152,33 @@ int clr_compile_only(const char *source, int n_options, const char **options, co
     return 0;
 }
 
+int clr_compile(const char *source, int n_options, const char **options, const char *arch,
+                void **binary, size_t *size) {
+    if (!source || !binary || !size) return fail("null argument");
+    std::vector<char> code;
+    if (int rc = compile(source, n_options, options, arch ? arch : "gfx950", code)) return rc;
+    void *copy = malloc(code.size() ? code.size() : 1);
+    if (!copy) return fail("out of memory");
+    memcpy(copy, code.data(), code.size());
+    *binary = copy;
+    *size = code.size();
+    return 0;
+}
+
+void clr_binary_free(void *binary) { free(binary); }
+
+int clr_compiler_version(int *major, int *minor) {
+    int a = 0, b = 0;
+    if (hiprtcVersion(&a, &b) != HIPRTC_SUCCESS) return fail("hiprtcVersion failed");
+    if (major) *major = a;
+    if (minor) *minor = b;
+    return 0;
+}
+
+namespace {
+int load_program(clr_ctx *ctx, const void *binary, clr_program **out);
+}
+
 int clr_program_build(clr_ctx *ctx, const char *source, int n_options, const char **options,
                       clr_program **out) {
     if (int rc = set_device(ctx)) return rc;
@@ -159,9 +187,23 @@ int clr_program_build(clr_ctx *ctx, const char *source, int n_options, const cha
     CLR_TRY(hipGetDeviceProperties(&p, ctx->device));
     std::vector<char> code;
     if (int rc = compile(source, n_options, options, p.gcnArchName, code)) return rc;
+    return load_program(ctx, code.data(), out);
+}
+
+int clr_program_load(clr_ctx *ctx, const void *binary, size_t size, clr_program **out) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!binary || !out) return fail("null argument");
+    if (size < 4 || memcmp(binary, "\177ELF", 4) != 0)
+        if (size < 24 || memcmp(binary, "__CLANG_OFFLOAD_BUNDLE__", 24) != 0)
+            return fail("clr_program_load: not a code object");
+    return load_program(ctx, binary, out);
+}
+
+namespace {
+int load_program(clr_ctx *ctx, const void *binary, clr_program **out) {
     clr_program *prog = new clr_program;
     prog->ctx = ctx;
-    if (int rc = check(hipModuleLoadData(&prog->module, code.data()), "hipModuleLoadData")) {
+    if (int rc = check(hipModuleLoadData(&prog->module, binary), "hipModuleLoadData")) {
         delete prog;
         return rc;
     }
@@ -172,6 +214,7 @@ int clr_program_build(clr_ctx *ctx, const char *source, int n_options, const cha
     *out = prog;
     return 0;
 }
+}  // namespace
 
 int clr_program_destroy(clr_program *prog) {
     if (!prog) return 0;

@@ -135,3 +135,41 @@ CLR_FN float clr_over_length(float t, const clr_direction &dir, clr_guard_spec &
     g.lo = CLR_IMIN(g.lo, CLR_BITS(t));
     return clr_quotient_short(t, dir.len, dir.y);
 }
+
+// ---- affine transform with statically known zero coefficients
+// m[0..2].xyz = rows of the matrix, m[3].xyz = translation.  `skip` (a literal at the call site,
+// Renderer.affine_skip_mask) has bit 3*row+col set where the baked coefficient is zero and bit
+// 9+row set where the translation is non-zero.  For finite v a term with a zero coefficient is a
+// zero, so leaving it out changes nothing unless the whole sum is a zero (whose sign may then
+// differ).  The speculative version therefore shortens
+//   * directions: a zero component fails the guard (its square is tracked);
+//   * position rows with a non-zero translation: a zero sum is absorbed by the translation.
+// The generic version evaluates every term.
+CLR_FN float clr_row_dot(const float4 m, const vec3 v, const int skip) {
+    float r = 0.0f;
+    bool any = false;
+    if (!(skip & 1)) { r = m.x * v.x; any = true; }
+    if (!(skip & 2)) { r = any ? r + m.y * v.y : m.y * v.y; any = true; }
+    if (!(skip & 4)) { r = any ? r + m.z * v.z : m.z * v.z; }
+    return r;
+}
+
+CLR_FN vec3 clr_to_local_direction(const float4 *m, const vec3 v, const int, const clr_guard_safe &) {
+    return make_vec3(m[0].x * v.x + m[0].y * v.y + m[0].z * v.z,
+                     m[1].x * v.x + m[1].y * v.y + m[1].z * v.z,
+                     m[2].x * v.x + m[2].y * v.y + m[2].z * v.z);
+}
+CLR_FN vec3 clr_to_local_direction(const float4 *m, const vec3 v, const int skip, clr_guard_spec &) {
+    return make_vec3(clr_row_dot(m[0], v, skip & 7), clr_row_dot(m[1], v, (skip >> 3) & 7),
+                     clr_row_dot(m[2], v, (skip >> 6) & 7));
+}
+
+CLR_FN vec3 clr_to_local_position(const float4 *m, const vec3 v, const int skip, const clr_guard_safe &g) {
+    const vec3 r = clr_to_local_direction(m, v, skip, g);
+    return make_vec3(r.x + m[3].x, r.y + m[3].y, r.z + m[3].z);
+}
+CLR_FN vec3 clr_to_local_position(const float4 *m, const vec3 v, const int skip, clr_guard_spec &) {
+    return make_vec3(clr_row_dot(m[0], v, (skip & (1 << 9)) ? skip & 7 : 0) + m[3].x,
+                     clr_row_dot(m[1], v, (skip & (1 << 10)) ? (skip >> 3) & 7 : 0) + m[3].y,
+                     clr_row_dot(m[2], v, (skip & (1 << 11)) ? (skip >> 6) & 7 : 0) + m[3].z);
+}

@@ -53,11 +53,21 @@ CLR_FN void clr_closest_hit(const vec3 pos, const vec3 ray, float &isec_dist, ui
     CLR_G &clr_g)
 {
 ### for tracer, count, offset in renderer.object_groups
-    #pragma unroll {{ count if renderer.bake_parameters else [count, 8]|min }}
+### set group = loop.index0
+### if renderer.bake_parameters
+    ### for i in range(count)
+    {{ tracer.tracer_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject,
+        last_whichobject, last_which_subobject, inside, vector_data, integer_data,
+        {{ offset+1+i }}, clr_params + {{ renderer.group_param_base[group] + i*renderer.group_param_stride[group] }},
+        {{ renderer.affine_skip_mask(offset+i) }}, clr_g);
+    ### endfor
+### else
+    #pragma unroll {{ [count, 8]|min }}
     for (int i = 0; i < {{ count }}; ++i)
         {{ tracer.tracer_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject,
             last_whichobject, last_which_subobject, inside, vector_data, integer_data,
-            {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[loop.index0] }} + i*{{ renderer.group_param_stride[loop.index0] }}, clr_g);
+            {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[group] }} + i*{{ renderer.group_param_stride[group] }}, 0, clr_g);
+### endif
 ### endfor
 }
 
@@ -91,12 +101,23 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
     const vec3 ray = light_dir.unit;
     float shadow_mask = 1.0f;
 ### for tracer, count, offset in renderer.object_groups
-    #pragma unroll {{ count if renderer.bake_parameters else [count, 8]|min }}
+### set group = loop.index0
+### if renderer.bake_parameters
+    ### for i in range(count)
+    if ({{ offset+1+i }} != light_id)
+        {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,
+            shadow_mask, vector_data, integer_data,
+            {{ offset+1+i }}, clr_params + {{ renderer.group_param_base[group] + i*renderer.group_param_stride[group] }},
+            {{ renderer.affine_skip_mask(offset+i) }}, clr_g);
+    ### endfor
+### else
+    #pragma unroll {{ [count, 8]|min }}
     for (int i = 0; i < {{ count }}; ++i)
         if ({{ offset+1 }} + i != light_id)
             {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,
                 shadow_mask, vector_data, integer_data,
-                {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[loop.index0] }} + i*{{ renderer.group_param_stride[loop.index0] }}, clr_g);
+                {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[group] }} + i*{{ renderer.group_param_stride[group] }}, 0, clr_g);
+### endif
 ### endfor
     return shadow_mask;
 }

@@ -68,7 +68,7 @@ template<class CLR_G> CLR_FN void {{ obj.tracer_kernel_name }}(
     const vec3 pos, const vec3 ray, float &isec_dist, uint &whichobject, uint &which_subobject,
     const uint last_whichobject, const uint last_which_subobject, const uint inside,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-    const int object_id, const float4 *P, CLR_G &clr_g)
+    const int object_id, const float4 *P, const int affine_skip, CLR_G &clr_g)
 {
     const bool within = inside == (uint)object_id,
                on_surface = last_whichobject == (uint)object_id;
@@ -79,8 +79,8 @@ template<class CLR_G> CLR_FN void {{ obj.tracer_kernel_name }}(
         uint cur_subobject = last_which_subobject;
         const float4 *p_inverse_affine = P + {{ obj.parameter_types()|length }};
 
-        const vec3 local_pos = apply_affine_transform(p_inverse_affine, pos);
-        const vec3 local_ray = apply_linear_transform(p_inverse_affine, ray);
+        const vec3 local_pos = clr_to_local_position(p_inverse_affine, pos, affine_skip, clr_g);
+        const vec3 local_ray = clr_to_local_direction(p_inverse_affine, ray, affine_skip, clr_g);
         // unit direction, stretch = |local_ray|; the four quotients by stretch share one reciprocal
         const clr_direction dir = clr_make_direction(local_ray, clr_g);
 
@@ -113,7 +113,7 @@ template<class CLR_G> CLR_FN void {{ obj.shadow_kernel_name }}(
     const vec3 pos, const vec3 ray, const float isec_dist,
     const uint whichobject, const uint which_subobject, const uint inside, float &shadow_mask,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-    const int object_id, const float4 *P, CLR_G &clr_g)
+    const int object_id, const float4 *P, const int affine_skip, CLR_G &clr_g)
 {
     uint subobject = which_subobject;
     const bool within = inside == (uint)object_id,
@@ -123,8 +123,8 @@ template<class CLR_G> CLR_FN void {{ obj.shadow_kernel_name }}(
     if (!on_surface || within) {
     ### endif
         const float4 *p_inverse_affine = P + {{ obj.parameter_types()|length }};
-        const vec3 local_pos = apply_affine_transform(p_inverse_affine, pos);
-        const vec3 local_ray = apply_linear_transform(p_inverse_affine, ray);
+        const vec3 local_pos = clr_to_local_position(p_inverse_affine, pos, affine_skip, clr_g);
+        const vec3 local_ray = clr_to_local_direction(p_inverse_affine, ray, affine_skip, clr_g);
         // unit direction, stretch = |local_ray|; the four quotients by stretch share one reciprocal
         const clr_direction dir = clr_make_direction(local_ray, clr_g);
 

@@ -131,6 +131,27 @@ class Renderer:
             self.group_param_base.append(self.object_param_base[offset])
             self.group_param_stride.append(strides.pop())
 
+    def affine_skip_mask(self, object_index):
+        """Which terms of an object's inverse-affine transform the speculative arithmetic may
+        leave out (clr_exact.inl): bit 3*row+col = the coefficient is zero, bit 9+row = the
+        translation of that row is non-zero (only then may the position row be shortened).
+        Rows of zeros are left alone.  Zero unless the parameters are baked into the program."""
+        if not (self.bake_parameters and self.speculate):
+            return 0
+        end = self.object_param_base[object_index] + self.scene.objects[object_index].tracer.param_slots
+        rows = self.param_table[end - 4:end, :3]
+        mask = 0
+        for r in range(3):
+            zeros = rows[r] == 0.0
+            if zeros.all():
+                continue
+            for c in range(3):
+                if zeros[c]:
+                    mask |= 1 << (3 * r + c)
+            if rows[3][r] != 0.0:
+                mask |= 1 << (9 + r)
+        return mask
+
     def param_table_literals(self):
         """The parameter table as exact C++17 hexadecimal float literals, row by row."""
         return [[float(v).hex() + 'f' for v in row] for row in self.param_table]
@@ -261,6 +282,12 @@ class Renderer:
         self.img = acc.new_vec3_array((self.n_pixels,))
         self.dev_vector_data = acc.to_device(self.vector_data)
         self.dev_integer_data = acc.to_device(self.integer_data)
+        self._build()
+        self._tape_capacity = 0
+        self.dev_rows = None
+
+    def _build(self):
+        acc = self.acc
         self.prog = acc.build_program(self.program_code, self.build_options)
         if self.n_param_slots and not self.bake_parameters:
             acc.set_global('clr_params', self.param_table)
@@ -268,8 +295,41 @@ class Renderer:
         if self.shader.rgb:
             acc.set_global('clr_material_colors', self.material_colors)
             acc.set_global('clr_material_scalars', self.material_scalars)
+
+    def tune_occupancy(self, candidates=(None, 3, 4, 5), passes=16, rounds=5, verbose=False):
+        """Pick the occupancy hint of the render kernel (second __launch_bounds__ argument) by
+        timing: the register allocation of these scene-specialised kernels lands on either side
+        of a waves-per-SIMD boundary more or less by chance, and one more resident wave or a few
+        spills move the run time by 5-20 % (profiles/r01c_occupancy.log).  Results do not depend
+        on the hint.  Builds the program once per candidate and leaves the fastest one in place;
+        the image accumulator and the random stream of the renderer are not touched."""
+        saved_rng, saved_img, saved_tape = self.rng, self.img, (
+            getattr(self, 'dev_pass_tape', None), getattr(self, 'dev_bounce_tape', None),
+            self.dev_rows, self._tape_capacity, getattr(self, '_resident_passes', 0))
+        self.rng = np.random.RandomState(20240229)
+        tape = self.make_tape(0, passes)
+        self.rng = saved_rng
+        self.img = self.acc.new_vec3_array((self.n_pixels,))
         self._tape_capacity = 0
-        self.dev_rows = None
+        self._upload_tape(tape)
+        timings = {}
+        for hint in candidates:
+            self.min_waves_per_simd = hint
+            self.program_code = Compiler(self).make_program()
+            self._build()
+            self.render_tape(tape)                                       # warm-up
+            timings[hint] = min(self.render_tape(tape)[0] for _ in range(rounds))
+            if verbose:
+                print('occupancy hint %s: %.3f ms' % (hint, timings[hint]))
+        best = min(timings, key=timings.get)
+        if best != self.min_waves_per_simd:
+            self.min_waves_per_simd = best
+            self.program_code = Compiler(self).make_program()
+            self._build()
+        self.img = saved_img
+        self.dev_pass_tape, self.dev_bounce_tape, self.dev_rows, self._tape_capacity, self._resident_passes = saved_tape
+        self.occupancy_timings = timings
+        return best
 
     def _upload_tape(self, tape):
         passes, bounces, rows = tape

@@ -49,3 +49,37 @@ def test_no_silent_fallback_without_a_device():
     with pytest.raises(accelerator.ClrError) as err:
         accelerator.Accelerator()
     assert 'no HIP device' in str(err.value)
+
+
+def test_program_store_and_child_compile(tmp_path, monkeypatch):
+    """program_cache: the child-process compile gives a code object like the in-process one; the
+    disk store exists only when CLRAY_CACHE_DIR asks for it and rejects altered files."""
+    from raytracer_amd import program_cache
+    source = 'extern "C" __global__ void k(float *p) { p[threadIdx.x] = 2.0f * p[threadIdx.x]; }\n'
+    monkeypatch.delenv('CLRAY_CACHE_DIR', raising=False)
+    assert program_cache.cache_dir() is None
+    here = program_cache.compile_here(source, ['-O3'], 'gfx950')
+    child = program_cache.compile_in_child(source, ['-O3'], 'gfx950')
+    assert here[:4] in (b'\x7fELF', b'__CL') and len(child) == len(here)
+    binary, how = program_cache.get_binary(source, ['-O3'], 'gfx950')
+    assert how in ('here', 'child') and len(binary) == len(here)
+    _, how = program_cache.get_binary(source, ['-O3'], 'gfx950')
+    assert how != 'cache'                               # nothing is kept unless asked for
+
+    monkeypatch.setenv('CLRAY_CACHE_DIR', str(tmp_path))
+    binary, how = program_cache.get_binary(source, ['-O3'], 'gfx950')
+    assert how != 'cache'
+    again, how = program_cache.get_binary(source, ['-O3'], 'gfx950')
+    assert how == 'cache' and again == binary
+    _, how = program_cache.get_binary(source, ['-O2'], 'gfx950')
+    assert how != 'cache'
+    for f in tmp_path.iterdir():                        # a flipped byte invalidates the file
+        blob = bytearray(f.read_bytes())
+        blob[-1] ^= 1
+        f.write_bytes(bytes(blob))
+    _, how = program_cache.get_binary(source, ['-O3'], 'gfx950')
+    assert how != 'cache'
+
+    with pytest.raises(Exception) as err:
+        program_cache.compile_in_child('this is not HIP', [], 'gfx950')
+    assert 'error' in str(err.value).lower()

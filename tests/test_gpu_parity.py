@@ -337,3 +337,22 @@ def test_speculative_arithmetic_and_path_restart_are_exact(name, options, regene
     r.render_tape(tape)
     oimg, _, _ = osc.render(tape, img=oimg)
     assert np.array_equal(bits(r.img.get()), bits(oimg))
+
+
+def test_occupancy_tuning_changes_neither_results_nor_state():
+    """Renderer.tune_occupancy rebuilds the program with different __launch_bounds__ hints and
+    keeps the fastest; image accumulator, resident tape and random stream stay as they were."""
+    from oracle import oracle
+    r = Renderer(load_scene('scene-three-objects', (64, 48)), seed=9)
+    tape = r.make_tape(0, 4)
+    r.upload_tape(tape)
+    r.render_resident(0, 2)
+    before = r.img.get().copy()
+    state = r.rng.get_state()[1].copy()
+    best = r.tune_occupancy(candidates=(None, 3, 4), passes=1, rounds=1)
+    assert best in (None, 3, 4) and set(r.occupancy_timings) == {None, 3, 4}
+    assert np.array_equal(r.rng.get_state()[1], state)
+    assert np.array_equal(bits(r.img.get()), bits(before))
+    r.render_resident(2, 2)
+    oimg, _, _ = oracle.OracleScene(r).render(tape)
+    assert np.array_equal(bits(r.img.get()), bits(oimg))

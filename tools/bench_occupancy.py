@@ -6,10 +6,10 @@ from raytracer_amd.renderer import Renderer
 
 def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
     rs, tape = {}, None
-    for w in (None, 4, 5, 6, 8):
+    for w in [(spec, hint) for spec in (False, True) for hint in (None, 2, 3, 4, 5)]:
         scene = runpy.run_path('raytracer_amd/scenes/%s.py' % scene_name)['scene']
         scene.image.size = size
-        r = Renderer(scene, seed=0, min_waves_per_simd=w)
+        r = Renderer(scene, seed=0, min_waves_per_simd=w[1], speculate=w[0])
         if tape is None:
             tape = r.make_tape(0, passes)
         r.upload_tape(tape)
@@ -24,7 +24,7 @@ def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
         r.img.fill(0); r.render_resident(0, passes)
         img = r.img.get()
         if ref is None: ref = img
-        print('waves/SIMD hint', w, 'median %.3f ms' % np.median(times[w]), 'min %.3f' % min(times[w]),
+        print('(speculate, waves/SIMD hint)', w, 'median %.3f ms' % np.median(times[w]), 'min %.3f' % min(times[w]),
               '%.0f Msamples/s' % (r.n_pixels * passes / np.median(times[w]) / 1e3), 'identical', np.array_equal(img, ref))
 
 if __name__ == '__main__':
