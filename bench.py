@@ -122,7 +122,9 @@ def main():
         per_rank = -(-(width * height) // world // 256) * 256      # whole blocks of 256 rays
         first = min(rank * per_rank, width * height)
         ray_range = (first, max(min(per_rank, width * height - first), 256))
+    hint = int(args.occupancy_hint) if args.occupancy_hint.isdigit() else None
     r = Renderer(scene, seed=args.seed, device_index=local_rank, ray_range=ray_range,
+                 min_waves_per_simd=hint,
                  build_options=args.build_options.split() if args.build_options else None,
                  bake_parameters=None if args.bake is None else bool(args.bake))
     r.regenerate = bool(args.regenerate)
@@ -131,8 +133,6 @@ def main():
         if rank == 0:
             print('occupancy tuning (ms per hint):', {str(k): round(v, 3) for k, v in r.occupancy_timings.items()},
                   file=sys.stderr)
-    elif args.occupancy_hint != 'none':
-        r.tune_occupancy(candidates=(int(args.occupancy_hint),))
     tiles = ray_range is not None
     frame = torch.zeros((width * height, 4), dtype=torch.float32, device='cuda')
     img = frame[ray_range[0]:ray_range[0] + ray_range[1]] if tiles else frame
