@@ -65,9 +65,17 @@ def cpu_baseline(renderer, tape, target_seconds):
     osc = oracle.OracleScene(renderer)
     threads = int(os.environ.get('OMP_NUM_THREADS', 0)) or min(os.cpu_count() or 1, 16)
     one = tuple(x[:1] if x is not None else None for x in tape)
-    _, _, flops = osc.render(one, n_threads=threads, count_flops=True)
-    flops_per_sample = flops / renderer.n_pixels
-    mesh_bytes_per_sample = osc.last_mesh_bytes / renderer.n_pixels
+    # algorithmic work per sample: counted over a few passes, because with the broadcast tape all
+    # pixels of a pass share their random directions and single passes differ by a factor of two
+    n_count = min(4, tape[0].shape[0])
+    flops = mesh_bytes = 0.0
+    for j in range(n_count):
+        single = tuple(x[j:j + 1] if x is not None else None for x in tape)
+        _, _, f = osc.render(single, n_threads=threads, count_flops=True)
+        flops += f
+        mesh_bytes += osc.last_mesh_bytes
+    flops_per_sample = flops / (renderer.n_pixels * n_count)
+    mesh_bytes_per_sample = mesh_bytes / (renderer.n_pixels * n_count)
     t0 = time.time()
     osc.render(one, n_threads=threads)
     t_one = time.time() - t0
