@@ -49,6 +49,8 @@ def main():
 
     image = Image(RAW_OUTPUT_FILE if args.append else None, settings=scene.image)
     renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device)
+    if scene.samples_per_pixel >= 64:
+        renderer.tune_occupancy(passes=8)       # pays off for long renders only
     acc = renderer.acc
 
     total = scene.samples_per_pixel
