@@ -128,6 +128,18 @@ int clr_octree_info(const clr_octree *oct, clr_octree_info_t *info);
 int clr_octree_copy(const clr_octree *oct, int *stream, int *flat_nodes, float *flat_tris);
 int clr_octree_destroy(clr_octree *oct);
 
+/* ---- mesh files (host only): replace read_off / read_zipper / remove_duplicate_faces
+ * (mesh_formats.py:14-40, 42-70, 72-82).  format: 0 = OFF, 1 = Stanford "zipper" ASCII PLY.
+ * One record per line; polygons are fan-triangulated around their first vertex; vertices are
+ * the first three numbers of a vertex record, as doubles.  clr_mesh_unique_faces writes the
+ * indices of the faces to keep (first occurrence of each SET of vertex indices). */
+typedef struct clr_mesh clr_mesh;
+int clr_mesh_read(const char *path, int format, clr_mesh **out);
+int clr_mesh_info(const clr_mesh *mesh, int *n_vertices, int *n_triangles);
+int clr_mesh_copy(const clr_mesh *mesh, double *vertices, int *triangles);
+int clr_mesh_destroy(clr_mesh *mesh);
+int clr_mesh_unique_faces(const int *faces, int n_faces, int *kept, int *n_kept);
+
 #ifdef __cplusplus
 }
 #endif

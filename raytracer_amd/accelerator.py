@@ -84,6 +84,11 @@ def load_library():
         'clr_octree_info': (ci, [vp, P(OctreeInfo)]),
         'clr_octree_copy': (ci, [vp, vp, vp, vp]),
         'clr_octree_destroy': (ci, [vp]),
+        'clr_mesh_read': (ci, [cp, ci, P(vp)]),
+        'clr_mesh_info': (ci, [vp, P(ci), P(ci)]),
+        'clr_mesh_copy': (ci, [vp, vp, vp]),
+        'clr_mesh_destroy': (ci, [vp]),
+        'clr_mesh_unique_faces': (ci, [vp, ci, vp, P(ci)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -111,6 +116,42 @@ def compile_only(source, options=(), arch='gfx950'):
     size = ctypes.c_size_t(0)
     _check(lib.clr_compile_only(source.encode('ascii'), n, arr, arch.encode(), ctypes.byref(size)))
     return size.value
+
+
+MESH_FORMATS = {'off': 0, 'zipper': 1, 'ply': 1}
+
+
+def read_mesh(path, fmt=None):
+    """Native reader for OFF / Stanford zipper files: (vertices float64 (n, 3), triangles int32
+    (m, 3)), the arrays the reference's readers return as nested lists."""
+    lib = load_library()
+    if fmt is None:
+        fmt = os.path.splitext(path)[1].lstrip('.').lower()
+    if fmt not in MESH_FORMATS:
+        raise ClrError("unknown mesh format %r (known: off, zipper/ply)" % fmt)
+    handle = ctypes.c_void_p()
+    _check(lib.clr_mesh_read(os.fsencode(path), MESH_FORMATS[fmt], ctypes.byref(handle)))
+    try:
+        nv, nt = ctypes.c_int(0), ctypes.c_int(0)
+        _check(lib.clr_mesh_info(handle, ctypes.byref(nv), ctypes.byref(nt)))
+        vertices = np.empty((nv.value, 3), dtype=np.float64)
+        triangles = np.empty((nt.value, 3), dtype=np.int32)
+        _check(lib.clr_mesh_copy(handle, vertices.ctypes.data_as(ctypes.c_void_p),
+                                 triangles.ctypes.data_as(ctypes.c_void_p)))
+    finally:
+        lib.clr_mesh_destroy(handle)
+    return vertices, triangles
+
+
+def unique_faces(faces):
+    """Indices of the faces that remove_duplicate_faces keeps (first of each vertex set)."""
+    lib = load_library()
+    faces = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+    kept = np.empty(faces.shape[0], dtype=np.int32)
+    n = ctypes.c_int(0)
+    _check(lib.clr_mesh_unique_faces(faces.ctypes.data_as(ctypes.c_void_p), faces.shape[0],
+                                     kept.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)))
+    return kept[:n.value]
 
 
 def build_octree(vertices, faces, max_depth, max_faces_per_leaf):

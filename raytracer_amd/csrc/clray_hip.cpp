@@ -93,6 +93,9 @@ int launch(clr_ctx *ctx, hipFunction_t fn, const unsigned grid[3], const unsigne
 
 }  // namespace
 
+// lets the other translation units of the library report through clr_last_error
+extern "C" __attribute__((visibility("hidden"))) void clr_set_error(const char *text) { g_error = text; }
+
 extern "C" {
 
 const char *clr_last_error(void) { return g_error.c_str(); }

@@ -385,3 +385,24 @@ def remove_duplicate_faces(faces, verbose=False):
         seen.add(key)
         unique.append(face)
     return unique
+
+
+# ---- native counterparts (csrc/mesh_io.cpp) for large files: same records, numpy arrays out
+def read_mesh_file(path, fmt=None, dedupe=False):
+    """(vertices (n, 3) float64, triangles (m, 3) int32) of an OFF or zipper file, parsed by the
+    native reader; dedupe=True also drops duplicate faces as remove_duplicate_faces does."""
+    from ..accelerator import read_mesh, unique_faces
+    vertices, triangles = read_mesh(path, fmt)
+    if dedupe:
+        triangles = triangles[unique_faces(triangles)]
+    return vertices, triangles
+
+
+def write_off(path, vertices, faces):
+    """Plain OFF writer (the reference only reads), used to build large synthetic inputs."""
+    vertices = numpy.asarray(vertices, dtype=numpy.float64)
+    faces = numpy.asarray(faces, dtype=numpy.int64)
+    with open(path, 'w') as f:
+        f.write('OFF\n%d %d 0\n' % (vertices.shape[0], faces.shape[0]))
+        numpy.savetxt(f, vertices, fmt='%.9g')
+        numpy.savetxt(f, numpy.hstack([numpy.full((faces.shape[0], 1), faces.shape[1]), faces]), fmt='%d')
