@@ -72,7 +72,12 @@ def main():
             if not args.no_window:
                 image.show(imgdata)
             image.save_raw(RAW_OUTPUT_FILE, imgdata)
-            image.save_png(PNG_OUTPUT_FILE, imgdata)
+            try:
+                # 8-bit image straight from the device accumulator (tonemap.py)
+                from PIL import Image as PilImage
+                PilImage.fromarray(renderer.get_display_image(scene.image, base=image.data), 'RGB').save(PNG_OUTPUT_FILE)
+            except NotImplementedError:
+                image.save_png(PNG_OUTPUT_FILE, imgdata)        # flares etc.: host pipeline
             acc.output_profiling_info()
             step = args.itr_per_refresh if done >= args.itr_per_refresh else max(1, args.itr_per_refresh // 10)
             next_refresh = min(done + step, total)

@@ -298,7 +298,7 @@ class Accelerator:
         info['ta'] += host_seconds
 
     def call(self, kernel_name, ndrange_size, buffer_args, value_args=(), work_group_size=None,
-             stream=None):
+             stream=None, prog=None):
         """Launch a kernel of the program over `ndrange_size` work items (1-D or 2-D)."""
         t0 = time.time()
         if isinstance(ndrange_size, int):
@@ -315,13 +315,15 @@ class Accelerator:
                 holders.append(ctypes.c_void_p(0))
             elif isinstance(a, (np.integer, int)):
                 holders.append(ctypes.c_int(int(a)))
+            elif isinstance(a, np.float64):
+                holders.append(ctypes.c_double(float(a)))      # a Python float stays a C float
             elif isinstance(a, (np.floating, float)):
                 holders.append(ctypes.c_float(float(a)))
             else:
                 raise TypeError("unsupported kernel argument %r" % (a,))
         argv = (ctypes.c_void_p * len(holders))(*[ctypes.cast(ctypes.pointer(h), ctypes.c_void_p) for h in holders])
         ms = ctypes.c_float(0)
-        _check(self.lib.clr_launch(self.prog, kernel_name.encode(), (ctypes.c_uint * 3)(*grid),
+        _check(self.lib.clr_launch(prog if prog is not None else self.prog, kernel_name.encode(), (ctypes.c_uint * 3)(*grid),
                                    (ctypes.c_uint * 3)(*block), len(holders), argv, stream,
                                    ctypes.byref(ms)))
         self._record(kernel_name, ms.value * 1e-3, time.time() - t0)

@@ -427,6 +427,19 @@ class Renderer:
         """Sum over all passes so far, (H, W, 3) (reference renderer.py:24-28)."""
         return self.unpermute(self.img.get().astype(np.float32)[:, 0:3]).astype(np.float64)
 
+    def get_display_image(self, settings=None, base=None):
+        """8-bit (H, W, 3) image of the sums so far, tone-mapped on the device (tonemap.py);
+        `base` = earlier sums to add.  Raises NotImplementedError for settings the device path
+        does not cover (flares, other reference functions): use imgutils.Image then."""
+        from .tonemap import DeviceToneMapper
+        if getattr(self, '_tone_mapper', None) is None:
+            self._tone_mapper = DeviceToneMapper(self)
+            self._tone_base = None
+        if base is not self._tone_base:
+            self._tone_mapper.set_base(base)
+            self._tone_base = base
+        return self._tone_mapper.to_24bit(settings if settings is not None else self.scene.image)
+
     def rays_per_sample(self):
         return self.n_pixels
 

@@ -61,3 +61,11 @@ def test_large_scenes_keep_parameters_in_constant_memory():
     big = Renderer(load_scene('scene-stairs-small', (16, 8)), device=False, seed=0, bake_parameters=False)
     assert '__constant__ float4 clr_params[' in big.program_code
     assert accelerator.compile_only(big.program_code, big.build_options) > 1000
+
+
+def test_tone_mapping_program_compiles_for_gfx950():
+    import os
+    from raytracer_amd import accelerator
+    from raytracer_amd.hip_compiler import TEMPLATE_DIR
+    source = open(os.path.join(TEMPLATE_DIR, 'tonemap.hip')).read()
+    assert accelerator.compile_only(source, ['-O3']) > 1000

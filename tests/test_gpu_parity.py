@@ -356,3 +356,25 @@ def test_occupancy_tuning_changes_neither_results_nor_state():
     r.render_resident(2, 2)
     oimg, _, _ = oracle.OracleScene(r).render(tape)
     assert np.array_equal(bits(r.img.get()), bits(oimg))
+
+
+@pytest.mark.parametrize('low_norm', ['min', None])
+def test_device_tone_mapping_matches_host_pipeline(low_norm):
+    """Renderer.get_display_image (tonemap.hip, binary64 on the device) against
+    imgutils.Image._to_24bit on the same accumulator, with and without earlier sums (--append)."""
+    from raytracer_amd.imgutils import Image, ColorEncodingSettings
+    r = Renderer(load_scene('scene-dev', (96, 64)), seed=4)
+    r.render_samples(0, 8)
+    settings = ColorEncodingSettings()
+    settings.low_normalization = np.min if low_norm == 'min' else None
+    sums = r.get_image()
+    for base in (None, sums * 0.5 + 0.01):
+        want = Image(data=base, settings=settings)._to_24bit(sums.copy())
+        got = r.get_display_image(settings, base=base)
+        assert got.shape == want.shape and got.dtype == np.uint8
+        diff = np.abs(got.astype(int) - want.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-5
+        assert want.std() > 10                                   # a real picture, not a flat field
+    settings.flares = True
+    with pytest.raises(NotImplementedError):
+        r.get_display_image(settings)
