@@ -243,9 +243,55 @@ PHI = 0.5 * (1 + math.sqrt(5))  # golden ratio
 
 
 class Parallelepiped(ConvexIntersection):
+    """Three slabs 0 <= x.n_i <= |ax_i| with n_i = ax_i / |ax_i|, measured from `origin`
+    (a box when the axes are orthogonal)."""
+
     def __init__(self, origin, ax1, ax2, ax3):
         ConvexIntersection.__init__(self, origin, [LayerComponent(ax) for ax in (ax1, ax2, ax3)])
         self.unique_tracer_id = ''
+
+    # ---- light interface (the reference has it for Sphere only, objects/sphere.py:12-25;
+    # SURVEY §8 row f4).  A box can then be a next-event light: `obj.bidirectional_light = True`.
+    def _world_frame(self):
+        """A corner and the three edge vectors, in world coordinates."""
+        normals = numpy.array([numpy.ravel(c.normal) for c in self.components], dtype=float)
+        heights = numpy.array([c.h for c in self.components], dtype=float)
+        # column j of `edges`: the displacement that raises slab coordinate j from 0 to h_j only
+        edges = numpy.linalg.inv(normals) * heights[None, :]
+        linear = numpy.asarray(self.coordinates.linear, dtype=float)
+        return numpy.ravel(self.coordinates.translation).astype(float), linear.dot(edges)
+
+    def _faces(self):
+        """[(corner, edge u, edge v, outward unit normal, area)] of the six faces."""
+        corner, edges = self._world_frame()
+        centre = corner + edges.sum(axis=1) / 2.0
+        faces = []
+        for i in range(3):
+            j, k = (i + 1) % 3, (i + 2) % 3
+            u, v = edges[:, j], edges[:, k]
+            normal = numpy.cross(u, v)
+            area = numpy.linalg.norm(normal)
+            normal = normal / area
+            for start in (corner, corner + edges[:, i]):
+                outward = normal if numpy.dot(start + (u + v) / 2.0 - centre, normal) > 0 else -normal
+                faces.append((start, u, v, outward, area))
+        return faces
+
+    def surface_area(self):
+        return float(sum(f[4] for f in self._faces()))
+
+    def random_surface_point_and_normal(self, rng=numpy.random):
+        faces = self._faces()
+        pick, a, b = rng.rand(3)
+        cumulative = numpy.cumsum([f[4] for f in faces])
+        start, u, v, outward, _ = faces[min(int(numpy.searchsorted(cumulative, pick * cumulative[-1], side='right')), 5)]
+        return start + a * u + b * v, outward
+
+    def center_and_min_sampling_distance(self):
+        corner, edges = self._world_frame()
+        signs = numpy.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=float)
+        half_diagonal = max(numpy.linalg.norm(edges.dot(sg)) for sg in signs) / 2.0
+        return corner + edges.sum(axis=1) / 2.0, 2.0 * half_diagonal
 
 
 class HyperplaneRepresentation(FixedConvexIntersection):

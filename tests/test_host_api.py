@@ -269,3 +269,27 @@ def test_speculation_is_off_for_marching_and_mesh_scenes():
     assert Renderer(load_scene('scene-dev', (16, 8)), device=False).speculate
     assert not Renderer(load_scene('scene-test', (16, 8)), device=False).speculate
     assert 'clr_segment_generic' not in Renderer(load_scene('scene-marchers', (16, 8)), device=False).program_code
+
+
+def test_parallelepiped_light_interface():
+    """Light interface of a box: sample points lie on the surface, normals point
+    outwards, faces are chosen in proportion to their area."""
+    from raytracer_amd.objects import Parallelepiped
+    box = Parallelepiped((1.0, -2.0, 0.5), (2, 0, 0), (0, 1, 0), (0, 0, 0.5))
+    box.rotate((0, 0, 1), 30)
+    assert abs(box.surface_area() - 2 * (2 * 1 + 2 * 0.5 + 1 * 0.5)) < 1e-9
+    centre, min_dist = box.center_and_min_sampling_distance()
+    assert abs(min_dist - np.sqrt(4 + 1 + 0.25)) < 1e-9
+    to_local = box.global_to_tracer_coordinate_transform().inverse()
+    rng = np.random.RandomState(0)
+    counts = {}
+    for _ in range(3000):
+        point, normal = box.random_surface_point_and_normal(rng)
+        assert abs(np.linalg.norm(normal) - 1) < 1e-12 and np.dot(point - centre, normal) > 0
+        local = to_local(point) if callable(to_local) else None
+        slab = np.array([np.dot(np.ravel(c.normal), local) / c.h for c in box.components])
+        on_face = np.isclose(slab, 0, atol=1e-9) | np.isclose(slab, 1, atol=1e-9)
+        assert on_face.sum() >= 1 and ((slab > -1e-9) & (slab < 1 + 1e-9)).all()
+        counts[int(np.argmax(on_face))] = counts.get(int(np.argmax(on_face)), 0) + 1
+    share = np.array([counts[i] for i in range(3)]) / 3000.0       # faces normal to x, y, z
+    assert np.allclose(share, np.array([0.5, 1.0, 2.0]) / 3.5, atol=0.03)
