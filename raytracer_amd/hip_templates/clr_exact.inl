@@ -19,8 +19,8 @@
 //
 // Speculation.  The short sequences carry no range tests.  Instead the operands are folded into
 // two running bounds (clr_guard_spec) and the caller checks the bounds once per path segment: if
-// they left the range the segment is computed again from its saved state with the generic
-// arithmetic (clr_guard_safe).  Generated functions are templates over the guard type, so both
+// they left the range the lane starts the path of that pass again and walks it with the generic
+// arithmetic (clr_guard_safe; main.hip).  Generated functions are templates over the guard type, so both
 // versions come from one source text.  The bounds are kept on the bit patterns with integer
 // min / max (the operands tracked are non-negative: squares, lengths, distances, discriminants;
 // a negative one or a NaN lands outside the range):

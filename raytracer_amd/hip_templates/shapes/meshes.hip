@@ -91,9 +91,13 @@
     not in scratch memory as a dynamically indexed private array would. -#}
 
 ### macro flat_triangle_loop()
+    // the record of triangle j+1 is requested before triangle j is tested: the traversal is
+    // bound by memory latency, not by arithmetic
+    const float4 * __restrict__ rec = tris + 3*first_triangle;
+    float4 n0 = rec[0], n1 = rec[1], n2 = rec[2];
     for (int j = 0; j < n_leaf_triangles; ++j) {
-        const float4 * __restrict__ rec = tris + 3*(first_triangle + j);
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const float4 r0 = n0, r1 = n1, r2 = n2;
+        if (j + 1 < n_leaf_triangles) { n0 = rec[3*j + 3]; n1 = rec[3*j + 4]; n2 = rec[3*j + 5]; }
         const int face_index = __float_as_int(r0.w);
         if (prev_face == (uint)face_index && on_surface) continue;
         const vec3 va = make_vec3(r0);
