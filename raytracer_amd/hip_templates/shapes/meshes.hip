@@ -120,7 +120,186 @@
     }
 ### endmacro
 
+
+{#- Flat layout with pooled triangle tests.  Measured on the 1 M-triangle scene, 93 % of the
+    traversal time is triangle tests and only a quarter of the lanes of a wave are busy in them
+    (rays that missed the root cube or already found their hit idle, leaves hold 1..50 faces).
+    Here every step has three phases:
+      A  each lane still traversing locates its leaf: (first record, count), exit distance;
+      B  the (lane, triangle) pairs of the whole wave form one list (prefix sum of the counts
+         over the lanes executing this call, kept in LDS by rank) that is dealt out evenly:
+         every lane - also one that has finished its own traversal - takes list entry
+         round*A + rank, finds the owner by binary search in the prefix sums, reads the owner's
+         ray from LDS and tests the triangle with the arithmetic of flat_triangle_loop; a hit
+         goes to the owner with a 64-bit LDS minimum on (t bits, index in the leaf), which is
+         the sequential rule "smallest t, earlier triangle on ties";
+      C  each lane reads its own minimum and either returns the hit or hops to the next cell.
+    A lane never leaves the loop before all lanes of the call are done. -#}
+### macro Octree_pooled__tracer(obj)
+    ### call tracer_function_base(obj)
+        const int LEVELS = {{ obj.levels }};
+        const int MAX_STEPS = {{ obj.max_steps }};
+        __shared__ int stack_lds[{{ obj.levels }} * 256];
+        __shared__ float4 pool_origin[256];            // origin.xyz, exit distance of the current leaf
+        __shared__ float4 pool_ray[256];               // ray.xyz, face to skip (int bits; -1 = none)
+        __shared__ int pool_first[256];                // first triangle record of the lane's leaf
+        __shared__ int pool_scan[256];                 // by rank inside the wave: inclusive prefix sums
+        __shared__ int pool_owner[256];                // by rank: thread index of the owner
+        __shared__ unsigned long long pool_best[256];  // per lane: min of (t bits << 32 | index in leaf)
+        int *stack = stack_lds + threadIdx.x;
+        #define STACK(level) stack[(level) * 256]
+        #define POOL_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
+
+        const int tid = threadIdx.x, wave_base = tid & ~63;
+        const unsigned long long exec_mask = __ballot(1);
+        const int rank = __popcll(exec_mask & ((1ull << (tid & 63)) - 1ull));
+        const int n_lanes = __popcll(exec_mask);
+
+        const vec3 slopes = make_vec3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
+        const int nx = slopes.x < 0.0f, ny = slopes.y < 0.0f, nz = slopes.z < 0.0f;   // entry walls
+        const vec3 far_walls = make_vec3((float)(1 - nx), (float)(1 - ny), (float)(1 - nz));
+        const int sx = 1 - 2*nx, sy = 1 - 2*ny, sz = 1 - 2*nz;
+
+        const vec3 rel = root_origin - origin;
+        vec3 t_in = slopes * (rel + make_vec3((float)nx, (float)ny, (float)nz)*root_size),
+             t_out = slopes * (rel + far_walls*root_size);
+        float seg_begin = fmaxf(fmaxf(t_in.x, t_in.y), t_in.z);
+        float seg_end = fminf(fminf(t_out.x, t_out.y), t_out.z);
+        bool done = seg_begin > seg_end || seg_end < 0.0f || seg_begin > t_limit;
+
+        const int * __restrict__ octree_data = integer_data + face_data_length;
+        const float4 * __restrict__ tris = vector_data + flat_tri_offset;
+
+        const uint prev_face = *p_subobject;
+        pool_ray[tid] = make_float4(ray.x, ray.y, ray.z, __int_as_float(on_surface ? (int)prev_face : -1));
+        pool_owner[wave_base + rank] = tid;
+
+        int cx = 0, cy = 0, cz = 0;       // integer cell coordinates at the current depth
+        int bx = 0, by = 0, bz = 0;       // their lowest bits (position inside the parent)
+        STACK(0) = root_data_offset;
+        int depth = 0;
+        float node_size = root_size;
+
+        for (int step = 0; step < MAX_STEPS && __any(!done); step++) {
+            // ---- A: locate the leaf under the current point
+            int count = 0, first = 0;
+            if (!done) {
+                vec3 ray_pos = origin + seg_begin * ray, node_origin = make_vec3(0.0f, 0.0f, 0.0f);
+                int head = 0, payload = 0, child_idx;
+                while (depth < LEVELS-1) {
+                    const int at = STACK(depth);
+                    head = octree_data[2*at];          // >= 0: leaf with that many triangles, -1: inner
+                    payload = octree_data[2*at+1];     // first triangle record / first child
+                    node_origin = root_origin + make_vec3((float)cx, (float)cy, (float)cz)*node_size;
+                    if (head >= 0) break;
+                    const vec3 rc = ray_pos - node_origin;
+                    const float half = 0.5f*node_size;
+                    bx = 1 - (rc.x < half); by = 1 - (rc.y < half); bz = 1 - (rc.z < half);
+                    child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
+                    STACK(depth+1) = payload + child_idx;
+                    cx = (cx << 1) | bx; cy = (cy << 1) | by; cz = (cz << 1) | bz;
+                    node_size *= 0.5f;
+                    depth++;
+                }
+                t_out = slopes * (node_origin - origin + far_walls*node_size);
+                seg_end = fminf(fminf(t_out.x, t_out.y), t_out.z);
+                if (head > 0) { count = head; first = payload; }
+            }
+            pool_origin[tid] = make_float4(origin.x, origin.y, origin.z, seg_end);
+            pool_first[tid] = first;
+            pool_best[tid] = ~0ull;
+
+            // ---- B: inclusive prefix sums of the counts over the lanes of this call
+            pool_scan[wave_base + rank] = count;
+            POOL_SYNC();
+            for (int d = 1; d < n_lanes; d <<= 1) {
+                const int mine = pool_scan[wave_base + rank];
+                const int left = rank >= d ? pool_scan[wave_base + rank - d] : 0;
+                POOL_SYNC();
+                pool_scan[wave_base + rank] = mine + left;
+                POOL_SYNC();
+            }
+            const int total = pool_scan[wave_base + n_lanes - 1];
+            for (int base = 0; base < total; base += n_lanes) {
+                const int w = base + rank;
+                if (w < total) {
+                    int lo = 0, hi = n_lanes - 1;                 // first rank whose prefix sum exceeds w
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (pool_scan[wave_base + mid] > w) hi = mid; else lo = mid + 1;
+                    }
+                    const int owner = pool_owner[wave_base + lo];
+                    const int j = w - (lo ? pool_scan[wave_base + lo - 1] : 0);
+                    const float4 o4 = pool_origin[owner], d4 = pool_ray[owner];
+                    const float4 * __restrict__ rec = tris + 3*(pool_first[owner] + j);
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    if (__float_as_int(r0.w) != __float_as_int(d4.w)) {
+                        const vec3 o_ray = make_vec3(d4), o_origin = make_vec3(o4);
+                        const vec3 va = make_vec3(r0);
+                        const vec3 e1 = make_vec3(r1);
+                        const vec3 e2 = make_vec3(r2);
+                        const vec3 pvec = cross(o_ray, e2);
+                        const float det = dot(e1, pvec);
+                        const float inv_det = 1.f / det;
+                        const vec3 tvec = o_origin - va;
+                        const float u = dot(tvec, pvec) * inv_det;
+                        if (!(u < 0.f || u > 1.f)) {
+                            const vec3 qvec = cross(tvec, e1);
+                            const float v = dot(o_ray, qvec) * inv_det;
+                            if (!(v < 0.f || u + v > 1.f)) {
+                                const float t = dot(e2, qvec) * inv_det;
+                                if (t > 0.0f && t < o4.w)
+                                    atomicMin(&pool_best[owner],
+                                              ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)j);
+                            }
+                        }
+                    }
+                }
+            }
+            POOL_SYNC();
+
+            // ---- C: own result, or hop to the neighbour cell
+            if (!done) {
+                const unsigned long long best = pool_best[tid];
+                if (best != ~0ull) {
+                    *t_hit = __uint_as_float((uint)(best >> 32));
+                    *p_subobject = (uint)__float_as_int(tris[3*(first + (int)(best & 0xffffffffull))].w);
+                    done = true;
+                }
+                else {
+                    int hx = 0, hy = 0, hz = 0;
+                    if (seg_end == t_out.x) hx = sx;
+                    else if (seg_end == t_out.y) hy = sy;
+                    else if (seg_end == t_out.z) hz = sz;
+                    while (depth > 0) {
+                        bx += hx; by += hy; bz += hz;
+                        if (bx >= 0 && bx <= 1 && by >= 0 && by <= 1 && bz >= 0 && bz <= 1) break;
+                        depth--;
+                        cx >>= 1; cy >>= 1; cz >>= 1;
+                        bx = cx & 1; by = cy & 1; bz = cz & 1;
+                        node_size *= 2.0f;
+                    }
+                    if (depth == 0) done = true;        // left the root cube
+                    else {
+                        cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
+                        const int child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
+                        STACK(depth) = octree_data[2*STACK(depth-1)+1] + child_idx;
+                        seg_begin = seg_end;
+                        if (seg_begin > t_limit) done = true;
+                    }
+                }
+            }
+            POOL_SYNC();
+        }
+        #undef STACK
+        #undef POOL_SYNC
+    ### endcall
+### endmacro
+
 ### macro Octree__tracer(obj)
+### if obj.pooled
+{{ Octree_pooled__tracer(obj) }}
+### else
     ### call tracer_function_base(obj)
         ### set flat = obj.layout == 'flat'
         const vec3 slopes = make_vec3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
@@ -243,6 +422,7 @@
         }
         #undef STACK
     ### endcall
+### endif
 ### endmacro
 
 ### macro Octree__normal(obj)

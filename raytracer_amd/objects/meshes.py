@@ -106,14 +106,20 @@ class Octree(Tracer):
     MAX_DEPTH = 7
 
     def __init__(self, triangle_mesh, max_depth=3, max_faces_per_leaf=5, builder='python',
-                 layout='stream', max_steps=300):
+                 layout='stream', max_steps=300, pooled=None):
         """builder: 'python' (restatement of the reference's construction) or 'native' (C++
         builder of libclray_hip.so, same tree, any size, max_depth up to 20).
         layout: 'stream' = the reference's integer stream; 'flat' = flattened nodes + per-leaf
         pre-gathered triangle records (needs the native builder).
-        max_steps: leaf-step budget of the traversal (300 in the reference)."""
+        max_steps: leaf-step budget of the traversal (300 in the reference).
+        pooled (flat layout only, default on): the triangle tests of all lanes of a wave are
+        pooled and dealt out evenly, so lanes whose ray left the mesh or sits in a small leaf
+        work on the leaves of the others (same tests, same results)."""
         if layout == 'flat':
             builder = 'native'
+        self.pooled = (layout == 'flat') if pooled is None else bool(pooled)
+        if self.pooled and layout != 'flat':
+            raise RuntimeError("pooled triangle tests need the flat layout")
         self.builder, self.layout, self.max_steps = builder, layout, max_steps
         mesh_pose = triangle_mesh.coordinates
         self.triangle_mesh = triangle_mesh
@@ -124,7 +130,7 @@ class Octree(Tracer):
         if self.max_depth >= self.__class__.MAX_DEPTH and builder == 'python':
             raise RuntimeError("max_depth >= MAX_DEPTH")
         if layout != 'stream' or max_steps != 300 or self.max_depth >= self.__class__.MAX_DEPTH:
-            self.unique_tracer_id = '_%s_d%d_s%d' % (layout, self.levels, max_steps)
+            self.unique_tracer_id = '_%s%s_d%d_s%d' % (layout, '_pooled' if self.pooled else '', self.levels, max_steps)
         self.build()
 
     @property

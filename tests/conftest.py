@@ -30,11 +30,14 @@ def load_scene(name, size=None, **overrides):
         api = types.SimpleNamespace(BoxScene=BoxScene, Sphere=shapes.Sphere, Cylinder=shapes.Cylinder,
                                     HalfSpace=shapes.HalfSpace)
         scene = golden_scenes.VARIANTS[name](api)
-    elif name.startswith('scene-mesh'):      # 'scene-mesh:<n_u>x<n_v>:<layout>'
+    elif name.startswith('scene-mesh'):      # 'scene-mesh:<n_u>x<n_v>:<layout>', layout 'flat-lanes' = flat, not pooled
         _, grid, layout = (name.split(':') + ['120x60', 'flat'])[:3] if ':' in name else (name, '120x60', 'flat')
         n_u, n_v = (int(v) for v in grid.split('x'))
         make = runpy.run_path(os.path.join(SCENE_DIR, 'scene-mesh.py'), run_name='lib')['make_scene']
-        scene = make(n_u, n_v, layout=layout)
+        if layout == 'flat-lanes':
+            scene = make(n_u, n_v, layout='flat', pooled=False)
+        else:
+            scene = make(n_u, n_v, layout=layout)
     else:
         scene = runpy.run_path(os.path.join(SCENE_DIR, name + '.py'))['scene']
     if size is not None:

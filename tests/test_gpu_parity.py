@@ -127,11 +127,14 @@ def test_tile_partition_reassembles_the_frame():
     assert np.array_equal(total, full)
 
 
-def test_flattened_octree_matches_reference_stream_and_oracle():
+@pytest.mark.parametrize('flat_layout', ['flat', 'flat-lanes'])
+def test_flattened_octree_matches_reference_stream_and_oracle(flat_layout):
     """BASELINE config C4 at reduced size (14 400 triangles): the flattened HBM layout with the
-    LDS stack, the reference-stream layout and the oracle (reference stream) agree bit for bit."""
+    LDS stack (triangle tests pooled over the wave, or per lane), the reference-stream layout
+    and the oracle (reference stream) agree bit for bit."""
     from oracle import oracle
-    flat = Renderer(load_scene('scene-mesh:120x60:flat', (96, 64)), seed=4)
+    flat = Renderer(load_scene('scene-mesh:120x60:' + flat_layout, (96, 64)), seed=4)
+    assert ('pool_best' in flat.program_code) == (flat_layout == 'flat')
     stream = Renderer(load_scene('scene-mesh:120x60:stream', (96, 64)), seed=4)
     osc = oracle.OracleScene(stream)
     tape = flat.make_tape(0, 4)
@@ -145,6 +148,7 @@ def test_flattened_octree_matches_reference_stream_and_oracle():
         assert np.array_equal(ids, ids_o)
         assert np.array_equal(bits(t), bits(t_o))
         assert np.array_equal(bits(n), bits(n_o))
+    flat.regenerate = True          # lanes of a wave in different passes and segments
     flat.render_tape(tape)
     stream.render_tape(tape)
     oimg, _, _ = osc.render(tape)
