@@ -211,7 +211,7 @@ def main():
         launch_samples = float(r.n_pixels) * P
         if mesh_bytes and args.scene == 'scene-mesh':
             # mesh traversal: HBM roofline on the algorithmic bytes of the flattened layout
-            # (8 B per node record visited, 48 B per triangle test)
+            # (8 B per node record visited, 36 B per triangle test)
             achieved = mesh_bytes * launch_samples / (avg_ms * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'kernel': 'clr_render', 'unit': 'GB/s', 'peak': PEAK_HBM_GBS,
                     'achieved': achieved, 'frac': achieved / PEAK_HBM_GBS,

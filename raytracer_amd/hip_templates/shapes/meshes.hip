@@ -90,19 +90,27 @@
     The per-lane stack of node positions lives in LDS (one column per lane: conflict-free),
     not in scratch memory as a dynamically indexed private array would. -#}
 
+{#- flat layout: 36-byte records (v0, e1, e2) back to back, 4-byte aligned; face ids apart -#}
+### macro flat_record_types()
+        typedef float clr_f4u __attribute__((ext_vector_type(4), aligned(4)));
+### endmacro
+
 ### macro flat_triangle_loop()
     // the record of triangle j+1 is requested before triangle j is tested: the traversal is
     // bound by memory latency, not by arithmetic
-    const float4 * __restrict__ rec = tris + 3*first_triangle;
-    float4 n0 = rec[0], n1 = rec[1], n2 = rec[2];
+    const float * __restrict__ rec = tris + 9*first_triangle;
+    clr_f4u n0 = *(const clr_f4u *)rec, n1 = *(const clr_f4u *)(rec + 4);
+    float n2 = rec[8];
     for (int j = 0; j < n_leaf_triangles; ++j) {
-        const float4 r0 = n0, r1 = n1, r2 = n2;
-        if (j + 1 < n_leaf_triangles) { n0 = rec[3*j + 3]; n1 = rec[3*j + 4]; n2 = rec[3*j + 5]; }
-        const int face_index = __float_as_int(r0.w);
-        if (prev_face == (uint)face_index && on_surface) continue;
-        const vec3 va = make_vec3(r0);
-        const vec3 e1 = make_vec3(r1);
-        const vec3 e2 = make_vec3(r2);
+        const clr_f4u r0 = n0, r1 = n1;
+        const float r2 = n2;
+        if (j + 1 < n_leaf_triangles) {
+            n0 = *(const clr_f4u *)(rec + 9*j + 9); n1 = *(const clr_f4u *)(rec + 9*j + 13); n2 = rec[9*j + 17];
+        }
+        if (on_surface && prev_face == (uint)tri_ids[first_triangle + j]) continue;
+        const vec3 va = make_vec3(r0.x, r0.y, r0.z);
+        const vec3 e1 = make_vec3(r0.w, r1.x, r1.y);
+        const vec3 e2 = make_vec3(r1.z, r1.w, r2);
         const vec3 pvec = cross(ray, e2);
         const float det = dot(e1, pvec);
         const float inv_det = 1.f / det;
@@ -115,11 +123,10 @@
         const float t = dot(e2, qvec) * inv_det;
         if (t > 0.0f && t < best_t) {
             best_t = t;
-            face = face_index;
+            face = tri_ids[first_triangle + j];
         }
     }
 ### endmacro
-
 
 {#- Flat layout with pooled triangle tests.  Measured on the 1 M-triangle scene, 93 % of the
     traversal time is triangle tests and only a quarter of the lanes of a wave are busy in them
@@ -168,7 +175,9 @@
         bool done = seg_begin > seg_end || seg_end < 0.0f || seg_begin > t_limit;
 
         const int * __restrict__ octree_data = integer_data + face_data_length;
-        const float4 * __restrict__ tris = vector_data + flat_tri_offset;
+        {{ flat_record_types() }}
+        const float * __restrict__ tris = (const float *)(vector_data + flat_tri_offset);
+        const int * __restrict__ tri_ids = octree_data + flat_ids_offset;
 
         const uint prev_face = *p_subobject;
         pool_ray[tid] = make_float4(ray.x, ray.y, ray.z, __int_as_float(on_surface ? (int)prev_face : -1));
@@ -231,13 +240,16 @@
                     const int owner = pool_owner[wave_base + lo];
                     const int j = w - (lo ? pool_scan[wave_base + lo - 1] : 0);
                     const float4 o4 = pool_origin[owner], d4 = pool_ray[owner];
-                    const float4 * __restrict__ rec = tris + 3*(pool_first[owner] + j);
-                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                    if (__float_as_int(r0.w) != __float_as_int(d4.w)) {
+                    const int record = pool_first[owner] + j;
+                    const float * __restrict__ rec = tris + 9*record;
+                    const clr_f4u r0 = *(const clr_f4u *)rec, r1 = *(const clr_f4u *)(rec + 4);
+                    const float r2 = rec[8];
+                    const int skip_face = __float_as_int(d4.w);
+                    if (skip_face < 0 || tri_ids[record] != skip_face) {
                         const vec3 o_ray = make_vec3(d4), o_origin = make_vec3(o4);
-                        const vec3 va = make_vec3(r0);
-                        const vec3 e1 = make_vec3(r1);
-                        const vec3 e2 = make_vec3(r2);
+                        const vec3 va = make_vec3(r0.x, r0.y, r0.z);
+                        const vec3 e1 = make_vec3(r0.w, r1.x, r1.y);
+                        const vec3 e2 = make_vec3(r1.z, r1.w, r2);
                         const vec3 pvec = cross(o_ray, e2);
                         const float det = dot(e1, pvec);
                         const float inv_det = 1.f / det;
@@ -263,7 +275,7 @@
                 const unsigned long long best = pool_best[tid];
                 if (best != ~0ull) {
                     *t_hit = __uint_as_float((uint)(best >> 32));
-                    *p_subobject = (uint)__float_as_int(tris[3*(first + (int)(best & 0xffffffffull))].w);
+                    *p_subobject = (uint)tri_ids[first + (int)(best & 0xffffffffull)];
                     done = true;
                 }
                 else {
@@ -316,7 +328,9 @@
 
         const int * __restrict__ octree_data = integer_data + face_data_length;
         ### if flat
-        const float4 * __restrict__ tris = vector_data + flat_tri_offset;
+        {{ flat_record_types() }}
+        const float * __restrict__ tris = (const float *)(vector_data + flat_tri_offset);
+        const int * __restrict__ tri_ids = octree_data + flat_ids_offset;
         ### endif
         const int LEVELS = {{ obj.levels }};
         const int MAX_STEPS = {{ obj.max_steps }};

@@ -246,11 +246,20 @@ class Octree(Tracer):
             vectors = numpy.zeros((numpy.asarray(data['vector']).shape[0], 4), dtype=numpy.float32)
             vectors[:, :3] = data['vector']
             self.flat_tri_offset = vectors.shape[0]
-            data['vector'] = numpy.vstack([vectors, native['flat_tris']])
-            data['integer'] = numpy.concatenate([faces, native['flat_nodes'].ravel()])
+            # per (leaf, face) record: v0, e1, e2 = 9 floats = 36 B, packed back to back; the
+            # face ids (needed only for the hit and for the self-intersection test) go to the
+            # integer data, so a triangle test reads 36 B instead of 48
+            recs = numpy.asarray(native['flat_tris'], dtype=numpy.float32).reshape(-1, 3, 4)
+            face_ids = numpy.ascontiguousarray(recs[:, 0, 3]).view(numpy.int32)
+            packed = numpy.ascontiguousarray(recs[:, :, :3]).reshape(-1)
+            packed = numpy.concatenate([packed, numpy.zeros((-packed.size) % 4, dtype=numpy.float32)])
+            data['vector'] = numpy.vstack([vectors, packed.reshape(-1, 4)])
+            nodes = native['flat_nodes'].ravel()
+            self.flat_ids_offset = nodes.size
+            data['integer'] = numpy.concatenate([faces, nodes, face_ids])
             self.root_data_offset = 0
         else:
-            self.flat_tri_offset = 0
+            self.flat_tri_offset = self.flat_ids_offset = 0
             self.root_data_offset = int(native['root_data_offset'])
             data['integer'] = numpy.concatenate([faces, native['stream']])
         return data
@@ -297,14 +306,14 @@ class Octree(Tracer):
     def parameter_declarations(self):
         decls = ['int n_vertices', 'int n_triangles', 'int root_data_offset',
                  'int face_data_length', 'float3 root_origin', 'float root_size']
-        return decls + ['int flat_tri_offset'] if self.layout == 'flat' else decls
+        return decls + ['int flat_tri_offset', 'int flat_ids_offset'] if self.layout == 'flat' else decls
 
     def parameter_values(self):
         if not hasattr(self, 'root_data_offset'):
             self.get_data()
         values = [self.triangle_mesh.n_vertices, self.triangle_mesh.n_faces,
                   self.root_data_offset, self.total_faces * 3, self.root.origin, self.root.size]
-        return values + [self.flat_tri_offset] if self.layout == 'flat' else values
+        return values + [self.flat_tri_offset, self.flat_ids_offset] if self.layout == 'flat' else values
 
 
 def face_bounding_spheres(vertices, faces):
