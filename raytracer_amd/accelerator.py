@@ -270,11 +270,13 @@ class Accelerator:
         _check(self.lib.clr_sync(self.ctx, stream))
 
     # ---- program
-    def build_program(self, prog_code, options=()):
+    def build_program(self, prog_code, options=(), keep_previous=False):
+        """Compile and load `prog_code` and make it the current program.  keep_previous leaves
+        the program that was current loaded (its handle stays valid: use_program / drop_program)."""
         if isinstance(options, str):
             options = options.split()
         self.last_code = prog_code
-        if self.prog is not None:
+        if self.prog is not None and not keep_previous:
             self.lib.clr_program_destroy(self.prog)
             self.prog = None
         # compile (system hiprtc, disk store: program_cache.py), then load the code object
@@ -285,6 +287,13 @@ class Accelerator:
         _check(self.lib.clr_program_load(self.ctx, binary, len(binary), ctypes.byref(prog)))
         self.prog = prog
         return prog
+
+    def use_program(self, prog):
+        self.prog = prog
+
+    def drop_program(self, prog):
+        if prog is not None and prog is not self.prog:
+            self.lib.clr_program_destroy(prog)
 
     def set_global(self, name, host):
         host = np.ascontiguousarray(host)

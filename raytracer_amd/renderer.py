@@ -286,9 +286,9 @@ class Renderer:
         self._tape_capacity = 0
         self.dev_rows = None
 
-    def _build(self):
+    def _build(self, keep_previous=False):
         acc = self.acc
-        self.prog = acc.build_program(self.program_code, self.build_options)
+        self.prog = acc.build_program(self.program_code, self.build_options, keep_previous=keep_previous)
         if self.n_param_slots and not self.bake_parameters:
             acc.set_global('clr_params', self.param_table)
         acc.set_global('clr_data_offsets', self.data_offsets)
@@ -296,7 +296,7 @@ class Renderer:
             acc.set_global('clr_material_colors', self.material_colors)
             acc.set_global('clr_material_scalars', self.material_scalars)
 
-    def tune_occupancy(self, candidates=(None, 3, 4, 5, 6), passes=16, rounds=5, verbose=False):
+    def tune_occupancy(self, candidates=(None, 3, 4, 5, 6), passes=16, rounds=7, verbose=False):
         """Pick the occupancy hint of the render kernel (second __launch_bounds__ argument) by
         timing: the register allocation of these scene-specialised kernels lands on either side
         of a waves-per-SIMD boundary more or less by chance, and one more resident wave or a few
@@ -312,20 +312,33 @@ class Renderer:
         self.img = self.acc.new_vec3_array((self.n_pixels,))
         self._tape_capacity = 0
         self._upload_tape(tape)
-        timings = {}
+        # all candidates stay loaded and are timed in interleaved rounds, so that clock and
+        # thermal drift hits them alike (differences of 3-5 % decide here)
+        previous = self.acc.prog
+        built = {}
         for hint in candidates:
             self.min_waves_per_simd = hint
-            self.program_code = Compiler(self).make_program()
-            self._build()
+            code = Compiler(self).make_program()
+            self.program_code = code
+            self._build(keep_previous=True)
+            built[hint] = (self.acc.prog, code)
             self.render_tape(tape)                                       # warm-up
-            timings[hint] = min(self.render_tape(tape)[0] for _ in range(rounds))
-            if verbose:
-                print('occupancy hint %s: %.3f ms' % (hint, timings[hint]))
+        self.acc.drop_program(previous)
+        samples = {hint: [] for hint in candidates}
+        for _ in range(rounds):
+            for hint in candidates:
+                self.acc.use_program(built[hint][0])
+                samples[hint].append(self.render_tape(tape)[0])
+        timings = {hint: float(np.median(v)) for hint, v in samples.items()}
+        if verbose:
+            print('occupancy hints, median ms:', timings)
         best = min(timings, key=timings.get)
-        if best != self.min_waves_per_simd:
-            self.min_waves_per_simd = best
-            self.program_code = Compiler(self).make_program()
-            self._build()
+        self.min_waves_per_simd = best
+        self.prog, self.program_code = built[best]
+        self.acc.use_program(self.prog)
+        for hint, (prog, _) in built.items():
+            if hint != best:
+                self.acc.drop_program(prog)
         self.img = saved_img
         self.dev_pass_tape, self.dev_bounce_tape, self.dev_rows, self._tape_capacity, self._resident_passes = saved_tape
         self.occupancy_timings = timings
