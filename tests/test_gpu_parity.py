@@ -420,3 +420,19 @@ def test_box_light_and_two_lights_bit_exact():
     r.render_samples(12, 384)
     a, b = r.get_image().mean(), plain.get_image().mean()
     assert abs(a - b) < 0.2 * b, (a, b)
+
+
+def test_pooled_and_per_lane_triangle_tests_agree_on_a_larger_mesh():
+    """Size-independent property of the octree traversal at 90 000 triangles, 640x360: dealing
+    the triangle tests of a wave out over its lanes changes no bit of the image, with lanes in
+    lock-step or regenerating their paths (lanes of a wave then sit in different segments)."""
+    images = []
+    for layout in ('flat', 'flat-lanes'):
+        for regenerate in (False, True):
+            r = Renderer(load_scene('scene-mesh:300x150:' + layout, (640, 360)), seed=6)
+            r.regenerate = regenerate
+            r.render_tape(r.make_tape(0, 3))
+            images.append(r.img.get())
+    assert images[0][:, :3].mean() > 0
+    for img in images[1:]:
+        assert np.array_equal(bits(img), bits(images[0]))
