@@ -186,9 +186,10 @@ def main():
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'strong' if tiles else 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s %dx%d, %d sample passes per step (RGB, next-event light, '
+        'config': {'workload': '%s %dx%d, %d sample passes per step (%s, next-event light, '
                                'max_bounces %d), broadcast random tape, build options %s'
-                               % (args.scene, width, height, P, scene.max_bounces, ' '.join(r.build_options)),
+                               % (args.scene, width, height, P, 'RGB' if r.shader.rgb else 'spectral', scene.max_bounces,
+                                  ' '.join(r.build_options)),
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'speculative_exact_arithmetic': bool(r.speculate),
                    'occupancy_hint': r.min_waves_per_simd,
