@@ -89,7 +89,8 @@ typedef struct clr_render_args {
     void *img;                 /* n_pixels x float4, running sum per pixel (blocked pixel order) */
     const void *cam;           /* n_pixels x float4, un-jittered primary ray per pixel */
     const void *pass_tape;     /* n_passes x 6 float4: camera sample per pass */
-    const void *bounce_tape;   /* n_passes x max_bounces x 5 float4: random tape per segment */
+    const void *bounce_tape;   /* n_passes x max_bounces x 5 float4: random tape per segment
+                                * (NULL for a program built for per-pixel random numbers) */
     const void *material_rows; /* spectral mode: n_passes x 10*(n_objects+1) floats; else NULL */
     const void *vector_data;   /* mesh vertices / normals (float4) or NULL */
     const void *integer_data;  /* mesh faces / octree stream (int32) or NULL */
@@ -97,6 +98,13 @@ typedef struct clr_render_args {
     int n_passes;
     int regenerate;            /* 1: a lane starts its next pass as soon as its path ends */
     void *debug_dump;          /* optional: max_bounces x n_pixels x 6 float4 (n_passes must be 1) */
+    /* per-pixel random numbers (programs generated with rng_mode 'philox'; no counterpart in the
+     * reference, whose random numbers are per frame): Philox key, global index of the first pass
+     * of this call and global ray index of pixel 0, which together with the segment number form
+     * the counter.  per_pixel_rng must say which kind of program `prog` is. */
+    int per_pixel_rng;
+    unsigned rng_seed_lo, rng_seed_hi;
+    int first_pass, first_ray;
 } clr_render_args;
 
 int clr_render_passes(clr_program *prog, const clr_render_args *args, void *stream,

@@ -41,6 +41,8 @@ static double orc_mesh_bytes_total;
 /* exp, log, tan shared with the device code so that both sides produce the same bits */
 #define CLR_MATH_FN static inline
 #include "../raytracer_amd/hip_templates/clr_math.inl"
+/* per-pixel random numbers and samplers, shared with the device code likewise */
+#include "../raytracer_amd/hip_templates/clr_rng.inl"
 
 /* ---- vector algebra, same definitions as hip_templates/static.hip ---- */
 static inline vec3 v3(float x, float y, float z) { vec3 v = {x, y, z}; return v; }
@@ -917,6 +919,30 @@ static bounce_sample load_bounce(const float *rec) {
     return B;
 }
 
+/* the same record from the pixel's own random numbers (no counterpart in the reference) */
+static bounce_sample draw_bounce(const orc_rng *g, unsigned pixel, unsigned pass, unsigned seg, int is_last) {
+    bounce_sample B;
+    clr_segment_draw d;
+    clr_draw_segment(g->seed_lo, g->seed_hi, pixel, pass, seg, g->n_lights > 0, &d);
+    B.rvec = v3(d.rvec[0], d.rvec[1], d.rvec[2]); B.p = d.p;
+    B.gauss = v3(d.gauss[0], d.gauss[1], d.gauss[2]); B.russian = d.russian;
+    B.light_point = v3(0.0f, 0.0f, 0.0f); B.light_area = 0.0f;
+    B.light_normal = v3(0.0f, 0.0f, 0.0f); B.min_light_sampling_distance = 0.0f;
+    B.light_center = v3(0.0f, 0.0f, 0.0f); B.light_id = 0;
+    if (g->n_lights > 0) {
+        int idx = (int)(d.light_u * (float)g->n_lights);
+        if (idx > g->n_lights - 1) idx = g->n_lights - 1;
+        const float *L = g->lights + 8 * idx;
+        B.light_normal = v3(d.light_dir[0], d.light_dir[1], d.light_dir[2]);
+        B.light_point = v3(L[0] + d.light_dir[0] * L[3], L[1] + d.light_dir[1] * L[3], L[2] + d.light_dir[2] * L[3]);
+        B.light_area = L[4];
+        B.min_light_sampling_distance = L[5];
+        B.light_center = v3(L[0], L[1], L[2]);
+        if (!is_last) memcpy(&B.light_id, L + 6, 4);
+    }
+    return B;
+}
+
 /* static.cl:109-131 + renderer.py:305-311 */
 static void start_path(const orc_scene *sc, path_state *s, const float *rec, vec3 base_ray) {
     const vec3 rot_ray = v3(dot3(v3p(rec), base_ray), dot3(v3p(rec + 4), base_ray), dot3(v3p(rec + 8), base_ray));
@@ -972,7 +998,7 @@ static int segment(const orc_scene *sc, const material_view *m, path_state *s, c
 
 int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, const float *bounce_tape,
                const float *material_rows, int n_pixels, int n_passes, float *img, float *dbg,
-               int n_threads, double *flops) {
+               int n_threads, double *flops, const orc_rng *rng) {
     const int stride = sc->n_objects + 1;
     const int row_len = 10 * stride;
     double total_flops = 0.0, total_bytes = 0.0;
@@ -995,7 +1021,10 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
             const vec3 cmask = v3p(prec + 20);
             material_view m = {sc, material_rows ? material_rows + (size_t)pass * row_len : 0, stride};
             for (int b = 0; b < sc->max_bounces; ++b) {
-                const bounce_sample B = load_bounce(bounce_tape + ((size_t)pass * sc->max_bounces + b) * ORC_BOUNCE_RECORD * 4);
+                const bounce_sample B = rng
+                    ? draw_bounce(rng, (unsigned)(rng->first_ray + k), (unsigned)(rng->first_pass + pass), (unsigned)b,
+                                  b == sc->max_bounces - 1)
+                    : load_bounce(bounce_tape + ((size_t)pass * sc->max_bounces + b) * ORC_BOUNCE_RECORD * 4);
                 float *d = dbg ? dbg + ((size_t)b * n_pixels + k) * ORC_DEBUG_RECORD * 4 : 0;
                 if (!segment(sc, &m, &s, &B, b == sc->max_bounces - 1, cmask, &acc, d)) break;
             }
@@ -1041,6 +1070,16 @@ int orc_first_hit(const orc_scene *sc, const float *cam, const float *pass_tape,
 float orc_math_exp(float x) { return clr_expf(x); }
 float orc_math_log(float x) { return clr_logf(x); }
 float orc_math_tan(float x) { return clr_tanf(x); }
+void orc_math_sincos_2pi(float u, float *s, float *c) { clr_sincos_2pi(u, s, c); }
+/* the 12 random numbers of one segment, for the statistical tests */
+void orc_rng_segment(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass, unsigned segment, float *out) {
+    clr_segment_draw d;
+    clr_draw_segment(seed_lo, seed_hi, pixel, pass, segment, 1, &d);
+    memcpy(out, &d, sizeof(d));
+}
+void orc_philox4x32(const unsigned *counter, const unsigned *key, unsigned *out) {
+    clr_philox4x32(counter[0], counter[1], counter[2], counter[3], key[0], key[1], out);
+}
 
 /* algorithmic mesh bytes of the last orc_render call (counting build only, else 0) */
 double orc_last_mesh_bytes(void) {

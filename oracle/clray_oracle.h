@@ -67,6 +67,15 @@ typedef struct orc_scene {
     float max_ray_length;
 } orc_scene;
 
+/* per-pixel random numbers (hip_templates/clr_rng.inl) instead of the bounce tape */
+typedef struct orc_rng {
+    unsigned seed_lo, seed_hi;
+    int first_pass;                     /* global index of the first pass of this call */
+    int first_ray;                      /* global ray index of pixel 0 (tile partitioning) */
+    int n_lights;
+    const float *lights;                /* per light 8 floats: centre xyz, R, area, min distance, id (int bits), 0 */
+} orc_rng;
+
 #define ORC_PASS_RECORD 6
 #define ORC_BOUNCE_RECORD 5
 #define ORC_DEBUG_RECORD 6
@@ -75,9 +84,11 @@ typedef struct orc_scene {
  * include/clray_hip.h.  dbg: optional max_bounces x n_pixels x 6 float4 (n_passes == 1).
  * flops: optional, receives the number of algorithmic FP32 operations executed
  * (counting rule: DESIGN.md).  Returns 0. */
+/* rng == NULL: the random numbers of every segment come from bounce_tape (shared by all pixels);
+ * else bounce_tape is ignored and every pixel draws its own */
 int orc_render(const orc_scene *scene, const float *cam, const float *pass_tape,
                const float *bounce_tape, const float *material_rows, int n_pixels, int n_passes,
-               float *img, float *dbg, int n_threads, double *flops);
+               float *img, float *dbg, int n_threads, double *flops, const orc_rng *rng);
 
 int orc_first_hit(const orc_scene *scene, const float *cam, const float *pass_tape, int n_pixels,
                   int *out_ids, float *out_t, float *out_normal /* n x 4 */, int n_threads);

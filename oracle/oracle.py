@@ -63,6 +63,12 @@ def build(force=False):
 _libs = {}
 
 
+class Rng(ctypes.Structure):
+    _fields_ = [('seed_lo', ctypes.c_uint), ('seed_hi', ctypes.c_uint), ('first_pass', ctypes.c_int),
+                ('first_ray', ctypes.c_int), ('n_lights', ctypes.c_int),
+                ('lights', ctypes.POINTER(ctypes.c_float))]
+
+
 def load(count_flops=False):
     name = 'libclray_oracle_flops.so' if count_flops else 'libclray_oracle.so'
     if name not in _libs:
@@ -71,7 +77,7 @@ def load(count_flops=False):
         fp = ctypes.POINTER(ctypes.c_float)
         lib.orc_render.restype = ctypes.c_int
         lib.orc_render.argtypes = [ctypes.POINTER(Scene), fp, fp, fp, fp, ctypes.c_int, ctypes.c_int,
-                                   fp, fp, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+                                   fp, fp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(Rng)]
         lib.orc_first_hit.restype = ctypes.c_int
         lib.orc_first_hit.argtypes = [ctypes.POINTER(Scene), fp, fp, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_int), fp, fp, ctypes.c_int]
@@ -296,10 +302,18 @@ class OracleScene:
             o.normal = ctypes.cast(getattr(lib, 'orc_gen_normal_%d' % n), ctypes.c_void_p).value
 
     # ---- runs
-    def render(self, tape, img=None, debug=False, n_threads=0, count_flops=False):
-        """Add the passes of `tape` to img (n_pixels x 4 float32).  Returns (img, dump, flops)."""
+    def render(self, tape, img=None, debug=False, n_threads=0, count_flops=False, first_pass=0):
+        """Add the passes of `tape` to img (n_pixels x 4 float32).  Returns (img, dump, flops).
+        With a renderer in per-pixel random number mode the bounce part of the tape is None and
+        `first_pass` is the global index of the tape's first pass."""
         r = self.renderer
         passes, bounces, rows = tape
+        rng = None
+        if getattr(r, 'rng_mode', 'tape') == 'philox':
+            lights = np.ascontiguousarray(r.light_table, np.float32)
+            rng = Rng(r.rng_seed & 0xffffffff, (r.rng_seed >> 32) & 0xffffffff, int(first_pass),
+                      r.ray_range[0] if r.ray_range else 0, lights.shape[0], _fptr(lights))
+            bounces = np.zeros(1, np.float32)
         n = passes.shape[0]
         if img is None:
             img = np.zeros((r.n_pixels, 4), dtype=np.float32)
@@ -314,7 +328,7 @@ class OracleScene:
         lib = load(count_flops)
         rc = lib.orc_render(ctypes.byref(self.c_scene), _fptr(r.host_cam), _fptr(passes), _fptr(bounces),
                             rows_p, r.n_pixels, n, _fptr(img), _fptr(dump) if dump is not None else None,
-                            n_threads, ctypes.byref(flops))
+                            n_threads, ctypes.byref(flops), ctypes.byref(rng) if rng is not None else None)
         assert rc == 0
         lib.orc_last_mesh_bytes.restype = ctypes.c_double
         self.last_mesh_bytes = lib.orc_last_mesh_bytes()

@@ -33,7 +33,9 @@ class RenderArgs(ctypes.Structure):
                 ('material_rows', ctypes.c_void_p), ('vector_data', ctypes.c_void_p),
                 ('integer_data', ctypes.c_void_p), ('n_pixels', ctypes.c_int),
                 ('n_passes', ctypes.c_int), ('regenerate', ctypes.c_int),
-                ('debug_dump', ctypes.c_void_p)]
+                ('debug_dump', ctypes.c_void_p), ('per_pixel_rng', ctypes.c_int),
+                ('rng_seed_lo', ctypes.c_uint), ('rng_seed_hi', ctypes.c_uint),
+                ('first_pass', ctypes.c_int), ('first_ray', ctypes.c_int)]
 
 
 class OctreeInfo(ctypes.Structure):

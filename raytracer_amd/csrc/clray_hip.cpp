@@ -41,6 +41,7 @@ struct clr_program {
     clr_ctx *ctx;
     hipModule_t module;
     hipFunction_t render, first_hit;
+    int rng_mode;      // 1: the program draws per-pixel random numbers, 0: it reads the bounce tape
 };
 
 namespace {
@@ -213,6 +214,11 @@ int load_program(clr_ctx *ctx, const void *binary, clr_program **out) {
     // a program for clr_launch only (unit kernels) need not hold the two fixed entry kernels
     if (hipModuleGetFunction(&prog->render, prog->module, "clr_render") != hipSuccess) prog->render = nullptr;
     if (hipModuleGetFunction(&prog->first_hit, prog->module, "clr_first_hit") != hipSuccess) prog->first_hit = nullptr;
+    prog->rng_mode = 0;
+    hipDeviceptr_t flag;
+    size_t flag_size = 0;
+    if (hipModuleGetGlobal(&flag, &flag_size, prog->module, "clr_rng_mode") == hipSuccess && flag_size == sizeof(int))
+        (void)hipMemcpyDtoH(&prog->rng_mode, flag, sizeof(int));
     (void)hipGetLastError();
     *out = prog;
     return 0;
@@ -288,8 +294,12 @@ int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream,
     if (int rc = set_device(prog->ctx)) return rc;
     if (!prog->render) return fail("clr_render_passes: the program has no kernel clr_render");
     if (a->n_pixels <= 0 || a->n_passes < 0) return fail("clr_render_passes: bad n_pixels / n_passes");
-    if (!a->img || !a->cam || !a->pass_tape || !a->bounce_tape)
-        return fail("clr_render_passes: img, cam, pass_tape and bounce_tape are required");
+    if (!a->img || !a->cam || !a->pass_tape)
+        return fail("clr_render_passes: img, cam and pass_tape are required");
+    if ((a->per_pixel_rng != 0) != (prog->rng_mode != 0))
+        return fail("clr_render_passes: per_pixel_rng does not match the random number mode the program was generated for");
+    if (!prog->rng_mode && !a->bounce_tape)
+        return fail("clr_render_passes: bounce_tape is required for a tape program");
     if (a->debug_dump && a->n_passes != 1)
         return fail("clr_render_passes: debug_dump needs n_passes == 1");
     if (a->n_passes == 0) { if (elapsed_ms) *elapsed_ms = 0.0f; return 0; }
@@ -298,7 +308,10 @@ int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream,
                *vd = a->vector_data, *id = a->integer_data;
     int n_pixels = a->n_pixels, n_passes = a->n_passes, regen = a->regenerate;
     void *dbg = a->debug_dump;
-    void *args[] = {&img, &cam, &pt, &bt, &mr, &vd, &id, &n_pixels, &n_passes, &regen, &dbg};
+    unsigned seed_lo = a->rng_seed_lo, seed_hi = a->rng_seed_hi;
+    int first_pass = a->first_pass, first_ray = a->first_ray;
+    void *args[] = {&img, &cam, &pt, &bt, &mr, &vd, &id, &n_pixels, &n_passes, &regen, &dbg,
+                    &seed_lo, &seed_hi, &first_pass, &first_ray};
     const unsigned grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
     const unsigned block[3] = {kBlock, 1, 1};
     return launch(prog->ctx, prog->render, grid, block, args, stream, elapsed_ms);

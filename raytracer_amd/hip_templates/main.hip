@@ -22,6 +22,14 @@ __constant__ float4 clr_material_colors[{{ 5*(n_objects+1) }}];
 __constant__ float clr_material_scalars[{{ 5*(n_objects+1) }}];
 ### endif
 
+// 1: every pixel draws its own random numbers (clr_rng.inl), 0: they come from the bounce tape;
+// read by the host library to check the launch arguments against the program
+__constant__ int clr_rng_mode = {{ 1 if renderer.rng_mode == 'philox' else 0 }};
+### if renderer.rng_mode == 'philox'
+// next-event lights (spheres): (centre, R), (area, minimum sampling distance, object id bits, 0)
+__constant__ float4 clr_lights[{{ [2*renderer.n_lights, 2]|max }}];
+### endif
+
 {% include 'shader.hip' %}
 
 // ---- shape functions
@@ -134,6 +142,33 @@ CLR_FN BounceSample clr_load_bounce(const float4 * __restrict__ rec) {
     return B;
 }
 
+### if renderer.rng_mode == 'philox'
+// the record of one segment from the pixel's own stream (same fields as the tape record)
+CLR_FN BounceSample clr_draw_bounce(const uint seed_lo, const uint seed_hi, const uint pixel,
+                                    const uint pass, const uint segment, const bool is_last) {
+    BounceSample B;
+    clr_segment_draw d;
+    clr_draw_segment(seed_lo, seed_hi, pixel, pass, segment, {{ 1 if renderer.n_lights else 0 }}, &d);
+    B.rvec = make_vec3(d.rvec[0], d.rvec[1], d.rvec[2]); B.p = d.p;
+    B.gauss = make_vec3(d.gauss[0], d.gauss[1], d.gauss[2]); B.russian = d.russian;
+    B.light_point = make_vec3(0.0f, 0.0f, 0.0f); B.light_area = 0.0f;
+    B.light_normal = make_vec3(0.0f, 0.0f, 0.0f); B.min_light_sampling_distance = 0.0f;
+    B.light_center = make_vec3(0.0f, 0.0f, 0.0f); B.light_id = 0;
+    ### if renderer.n_lights
+    int idx = (int)(d.light_u * {{ renderer.n_lights|float }}f);
+    if (idx > {{ renderer.n_lights - 1 }}) idx = {{ renderer.n_lights - 1 }};
+    const float4 L0 = clr_lights[2*idx], L1 = clr_lights[2*idx + 1];
+    B.light_normal = make_vec3(d.light_dir[0], d.light_dir[1], d.light_dir[2]);
+    B.light_point = make_vec3(L0.x + d.light_dir[0] * L0.w, L0.y + d.light_dir[1] * L0.w, L0.z + d.light_dir[2] * L0.w);
+    B.light_area = L1.x;
+    B.min_light_sampling_distance = L1.y;
+    B.light_center = make_vec3(L0);
+    if (!is_last) B.light_id = __float_as_int(L1.z);
+    ### endif
+    return B;
+}
+### endif
+
 // primary ray of one pass (static.cl:109-131): rows of the jitter rotation in rec[0..2],
 // rec[3] = (dof offset, sharp distance), rec[4] = (camera origin, initial path colour scale)
 CLR_FN void clr_start_path(PathState &s, const float4 * __restrict__ rec, const vec3 base_ray) {
@@ -228,7 +263,8 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
            const float4 * __restrict__ pass_tape, const float4 * __restrict__ bounce_tape,
            const float * __restrict__ material_rows,
            const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-           const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg)
+           const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg,
+           const uint rng_seed_lo, const uint rng_seed_hi, const int first_pass, const int first_ray)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_image = k < n_pixels;
@@ -262,8 +298,13 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
         }
         if (!__any(active)) break;
         if (active) {
-            const BounceSample B = clr_load_bounce(bounce_tape + ((size_t)pass * CLR_MAX_BOUNCES + segment) * CLR_BOUNCE_STRIDE);
             const bool is_last = segment == CLR_MAX_BOUNCES - 1;
+### if renderer.rng_mode == 'philox'
+            const BounceSample B = clr_draw_bounce(rng_seed_lo, rng_seed_hi, (uint)(first_ray + k),
+                                                   (uint)(first_pass + pass), (uint)segment, is_last);
+### else
+            const BounceSample B = clr_load_bounce(bounce_tape + ((size_t)pass * CLR_MAX_BOUNCES + segment) * CLR_BOUNCE_STRIDE);
+### endif
             float4 *d = dbg ? dbg + ((size_t)segment * n_pixels + k) * CLR_DBG_STRIDE : nullptr;
             const float *material_row = material_rows + (size_t)pass * CLR_MATERIAL_ROW;
 ### if renderer.speculate

@@ -62,6 +62,7 @@ static __device__ const clr_guard_safe clr_g = {};
 
 #define CLR_MATH_FN CLR_FN
 {% include 'clr_math.inl' %}
+{% include 'clr_rng.inl' %}
 
 // ---- interval arithmetic (static.cl:4-61); an interval is (x = begin, y = end)
 typedef vec2 ia_type;

@@ -27,13 +27,20 @@ class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
-                 min_waves_per_simd=None, speculate=None):
+                 min_waves_per_simd=None, speculate=None, rng_mode='tape'):
         self.scene = scene
         # tile partitioning: (first ray, count) in ray order; a contiguous range of ray
         # indices is a set of 4-pixel-wide column blocks of the frame (get_image_order)
         self.ray_range = ray_range
         self.shader = scene.shader(scene)
         self.rng = np.random.RandomState(seed)
+        # 'tape': the reference's random numbers, drawn on the host in its order and shared by
+        # all pixels of a pass (parity mode).  'philox': every pixel draws its own numbers on the
+        # device (hip_templates/clr_rng.inl); camera jitter and wavelength stay per pass.
+        if rng_mode not in ('tape', 'philox'):
+            raise ValueError("rng_mode must be 'tape' or 'philox'")
+        self.rng_mode = rng_mode
+        self.rng_seed = (0 if seed is None else int(seed)) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 & (2**64 - 1)
 
         self._group_objects()
         self._init_lights()
@@ -86,6 +93,19 @@ class Renderer:
         self.bidirectional_light_ids = [i for i, obj in enumerate(self.scene.objects)
                                         if obj.bidirectional_light]
         self.bidirectional = len(self.bidirectional_light_ids) > 0
+        self.n_lights = len(self.bidirectional_light_ids)
+        # per-pixel random numbers: the light points are drawn on the device, from this table
+        # (centre, R, area, minimum sampling distance, object id); spheres only
+        self.light_table = np.zeros((self.n_lights, 8), dtype=np.float32)
+        if self.rng_mode == 'philox':
+            for row, light_id in zip(self.light_table, self.bidirectional_light_ids):
+                tracer = self.scene.objects[light_id].tracer
+                if not hasattr(tracer, 'R') or not hasattr(tracer, '_check_no_distortion'):
+                    raise NotImplementedError("rng_mode='philox' samples sphere lights only")
+                tracer._check_no_distortion()
+                center, min_dist = tracer.center_and_min_sampling_distance()
+                row[0:3], row[3], row[4], row[5] = center, tracer.R, tracer.surface_area(), min_dist
+                row[6:7] = np.array([light_id + 1], dtype=np.int32).view(np.float32)
 
     def _collect_tracer_data(self):
         """Pack per-object parameters and mesh data (role of reference renderer.py:121-241).
@@ -241,7 +261,8 @@ class Renderer:
         scene = self.scene
         max_bounces = scene.max_bounces
         passes = np.zeros((n_passes, PASS_RECORD, 4), dtype=np.float32)
-        bounces = np.zeros((n_passes, max_bounces, BOUNCE_RECORD, 4), dtype=np.float32)
+        per_pixel = self.rng_mode == 'philox'        # then only the per-pass part is drawn here
+        bounces = None if per_pixel else np.zeros((n_passes, max_bounces, BOUNCE_RECORD, 4), dtype=np.float32)
         rows = None
         if not self.shader.rgb:
             rows = np.zeros((n_passes, self.shader.host_mat_y.shape[0]), dtype=np.float32)
@@ -255,7 +276,7 @@ class Renderer:
                 inv_pdf, rows[j], cmask = self.shader.sample_wavelength(self.rng.random_sample())
                 passes[j, 4, 3] = inv_pdf
                 passes[j, 5, 0:3] = cmask
-            for b in range(max_bounces if segments is None else int(segments[j])):
+            for b in range(0 if per_pixel else (max_bounces if segments is None else int(segments[j]))):
                 is_last = b == max_bounces - 1
                 rec = bounces[j, b]
                 if self.bidirectional:
@@ -292,6 +313,8 @@ class Renderer:
         if self.n_param_slots and not self.bake_parameters:
             acc.set_global('clr_params', self.param_table)
         acc.set_global('clr_data_offsets', self.data_offsets)
+        if self.rng_mode == 'philox' and self.n_lights:
+            acc.set_global('clr_lights', self.light_table)
         if self.shader.rgb:
             acc.set_global('clr_material_colors', self.material_colors)
             acc.set_global('clr_material_scalars', self.material_scalars)
@@ -350,11 +373,12 @@ class Renderer:
         n = passes.shape[0]
         if n > self._tape_capacity:
             self.dev_pass_tape = acc.new_array((n,) + passes.shape[1:], np.float32)
-            self.dev_bounce_tape = acc.new_array((n,) + bounces.shape[1:], np.float32)
+            self.dev_bounce_tape = acc.new_array((n,) + bounces.shape[1:], np.float32) if bounces is not None else None
             self.dev_rows = (acc.new_array((n, rows.shape[1]), np.float32) if rows is not None else None)
             self._tape_capacity = n
         self.dev_pass_tape[:n].set(passes)
-        self.dev_bounce_tape[:n].set(bounces)
+        if bounces is not None:
+            self.dev_bounce_tape[:n].set(bounces)
         if rows is not None:
             self.dev_rows[:n].set(rows)
 
@@ -364,11 +388,14 @@ class Renderer:
         from .accelerator import DeviceArray
         self.img = DeviceArray(self.acc, (self.n_pixels, 4), np.float32, ptr=int(device_ptr))
 
-    def upload_tape(self, tape):
-        """Make `tape` resident on the device; later launches pick pass ranges out of it."""
+    def upload_tape(self, tape, first_pass=0):
+        """Make `tape` resident on the device; later launches pick pass ranges out of it.
+        first_pass: global index of the tape's first pass (per-pixel random numbers count passes
+        globally)."""
         self._tape_capacity = 0
         self._upload_tape(tape)
         self._resident_passes = tape[0].shape[0]
+        self._resident_first_pass = int(first_pass)
 
     def render_resident(self, first, count, stream=None, timed=True):
         """Render passes [first, first + count) of the resident tape (no host transfer)."""
@@ -377,13 +404,20 @@ class Renderer:
         args = RenderArgs(
             img=self.img.ptr, cam=self.cam.ptr,
             pass_tape=self.dev_pass_tape[first:first + count].ptr,
-            bounce_tape=self.dev_bounce_tape[first:first + count].ptr, material_rows=rows,
+            bounce_tape=self.dev_bounce_tape[first:first + count].ptr if self.dev_bounce_tape is not None else None,
+            material_rows=rows,
             vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
             n_pixels=self.n_pixels, n_passes=count, regenerate=int(self.regenerate),
-            debug_dump=None)
+            debug_dump=None, **self._rng_args(self._resident_first_pass + first))
         return self.acc.render_passes(args, stream=stream, timed=timed)
 
-    def render_tape(self, tape, debug=False, stream=None, timed=True):
+    def _rng_args(self, first_pass):
+        """The per-pixel random number fields of clr_render_args."""
+        return dict(per_pixel_rng=int(self.rng_mode == 'philox'),
+                    rng_seed_lo=self.rng_seed & 0xffffffff, rng_seed_hi=(self.rng_seed >> 32) & 0xffffffff,
+                    first_pass=int(first_pass), first_ray=self.ray_range[0] if self.ray_range else 0)
+
+    def render_tape(self, tape, debug=False, stream=None, timed=True, first_pass=0):
         """Render the passes described by `tape` and add them to the image accumulator.
         Returns (kernel milliseconds, debug dump or None)."""
         n = tape[0].shape[0]
@@ -394,17 +428,17 @@ class Renderer:
                                       np.float32, zeros=True)
         args = RenderArgs(
             img=self.img.ptr, cam=self.cam.ptr, pass_tape=self.dev_pass_tape.ptr,
-            bounce_tape=self.dev_bounce_tape.ptr,
+            bounce_tape=self.dev_bounce_tape.ptr if self.dev_bounce_tape is not None else None,
             material_rows=self.dev_rows.ptr if self.dev_rows is not None else None,
             vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
             n_pixels=self.n_pixels, n_passes=n, regenerate=int(self.regenerate),
-            debug_dump=dump.ptr if dump is not None else None)
+            debug_dump=dump.ptr if dump is not None else None, **self._rng_args(first_pass))
         ms = self.acc.render_passes(args, stream=stream, timed=timed)
         return ms, (dump.get() if dump is not None else None)
 
     def render_samples(self, first_pass, n_passes):
         """Render passes [first_pass, first_pass + n_passes) with one kernel launch."""
-        ms, _ = self.render_tape(self.make_tape(first_pass, n_passes))
+        ms, _ = self.render_tape(self.make_tape(first_pass, n_passes), first_pass=first_pass)
         return ms
 
     def render_sample(self, sample_index):

@@ -45,3 +45,47 @@ def test_tan(lib):
     xs = np.float32(np.linspace(0.001, 1.5707, 20001))      # pi/2 * (1 - blur), blur in [0, 1)
     assert ulp_error(sweep(lib.orc_math_tan, xs), np.tan(xs.astype(np.float64))).max() < 3.5
     assert abs(lib.orc_math_tan(np.float32(np.pi / 2))) > 1e7
+
+
+def test_sincos_2pi(lib):
+    lib.orc_math_sincos_2pi.argtypes = [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    us = np.float32(np.concatenate([np.linspace(0, 1, 20001)[:-1], [0.25, 0.5, 0.75, 0.99999994]]))
+    s, c = ctypes.c_float(), ctypes.c_float()
+    got = []
+    for u in us:
+        lib.orc_math_sincos_2pi(float(u), ctypes.byref(s), ctypes.byref(c))
+        got.append((s.value, c.value))
+    got = np.array(got)
+    angle = 2 * np.pi * us.astype(np.float64)
+    assert np.abs(got[:, 0] - np.sin(angle)).max() < 3e-7
+    assert np.abs(got[:, 1] - np.cos(angle)).max() < 3e-7
+
+
+def test_philox_known_answers_and_sampler_statistics(lib):
+    """Philox-4x32-10 against the published known-answer vectors (Random123 kat_vectors), and
+    the moments of the per-segment samplers of hip_templates/clr_rng.inl."""
+    u4 = ctypes.c_uint * 4
+    u2 = ctypes.c_uint * 2
+    out = u4()
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for counter, key, want in kat:
+        lib.orc_philox4x32(u4(*counter), u2(*key), out)
+        assert tuple(out) == want
+    lib.orc_rng_segment.argtypes = [ctypes.c_uint] * 5 + [ctypes.POINTER(ctypes.c_float)]
+    buf = (ctypes.c_float * 12)()
+    draws = []
+    for pixel in range(4000):
+        lib.orc_rng_segment(7, 9, pixel, pixel % 5, pixel % 3, buf)
+        draws.append(list(buf))
+    d = np.array(draws, dtype=np.float64)      # rvec 0:3, p 3, gauss 4:7, russian 7, light_u 8, light_dir 9:12
+    for cols in (slice(0, 3), slice(9, 12)):
+        assert np.abs(np.linalg.norm(d[:, cols], axis=1) - 1).max() < 1e-6
+        assert np.abs(d[:, cols].mean(axis=0)).max() < 0.04
+    assert abs(d[:, 3].mean() - 0.5) < 0.02 and abs(d[:, 7].mean() - 0.5) < 0.02 and abs(d[:, 8].mean() - 0.5) < 0.02
+    assert (d[:, [3, 7, 8]] >= 0).all() and (d[:, [3, 7, 8]] < 1).all()
+    g = d[:, 4:7]
+    assert np.abs(g.mean(axis=0)).max() < 0.06 and np.abs(g.std(axis=0) - 1).max() < 0.05
+    assert np.abs(np.corrcoef(g.T) - np.eye(3)).max() < 0.06

@@ -436,3 +436,45 @@ def test_pooled_and_per_lane_triangle_tests_agree_on_a_larger_mesh():
     assert images[0][:, :3].mean() > 0
     for img in images[1:]:
         assert np.array_equal(bits(img), bits(images[0]))
+
+
+@pytest.mark.parametrize('name', ['scene-dev', 'scene-three-objects', 'scene-dev-spectral'])
+def test_per_pixel_random_numbers_match_oracle_and_tape_mode(name):
+    """rng_mode='philox' (hip_templates/clr_rng.inl; no counterpart in the reference): HIP equals
+    the oracle bit for bit, path regeneration changes nothing, launches can be split anywhere,
+    and the converged image agrees with the reference-style tape mode."""
+    from oracle import oracle
+    r = Renderer(load_scene(name, (64, 48)), seed=3, rng_mode='philox')
+    osc = oracle.OracleScene(r)
+    tape = r.make_tape(0, 6)
+    assert tape[1] is None
+    one = tuple(x[:1] if x is not None else None for x in tape)
+    _, dump = r.render_tape(one, debug=True)
+    oimg, odump, _ = osc.render(one, debug=True)
+    assert np.array_equal(bits(dump), bits(odump))
+    assert np.array_equal(bits(r.img.get()), bits(oimg))
+    rest = tuple(x[1:] if x is not None else None for x in tape)
+    r.regenerate = True
+    r.render_tape(rest, first_pass=1)
+    oimg, _, _ = osc.render(rest, img=oimg, first_pass=1)
+    assert np.array_equal(bits(r.img.get()), bits(oimg))
+    # one launch for all six passes gives the same sums
+    whole = Renderer(load_scene(name, (64, 48)), seed=3, rng_mode='philox')
+    whole.render_tape(whole.make_tape(0, 6))
+    assert np.array_equal(bits(whole.img.get()), bits(oimg))
+    # statistics: 256 passes per mode, image means within a few per cent
+    a = Renderer(load_scene(name, (64, 48)), seed=5, rng_mode='philox')
+    b = Renderer(load_scene(name, (64, 48)), seed=5)
+    a.render_samples(0, 256)
+    b.render_samples(0, 256)
+    ma, mb = a.get_image().mean(), b.get_image().mean()
+    assert abs(ma - mb) < 0.1 * mb, (ma, mb)
+
+
+def test_random_number_mode_of_program_and_launch_must_agree():
+    r = Renderer(load_scene('scene-dev', (32, 16)), seed=0)
+    tape = r.make_tape(0, 1)
+    r.rng_mode = 'philox'                       # launch arguments now claim the other mode
+    with pytest.raises(Exception) as err:
+        r.render_tape(tape)
+    assert 'random number mode' in str(err.value)
