@@ -38,7 +38,10 @@ def parse_args():
     ap.add_argument('--size', default='1920x1080')
     ap.add_argument('--mesh-grid', default='1000x500', help='scene-mesh: quads along / around the tube')
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--regenerate', type=int, default=0)
+    ap.add_argument('--regenerate', type=int, default=None, help='path regeneration 1/0 (default: on with --rng philox)')
+    ap.add_argument('--rng', choices=['tape', 'philox'], default='tape',
+                    help="tape: the reference's per-frame random numbers (parity mode, the default); "
+                         "philox: every pixel draws its own on the device")
     ap.add_argument('--build-options', default=None,
                     help='hiprtc options instead of the parity set (-O3 -ffp-contract=off)')
     ap.add_argument('--bake', type=int, default=None, help='1/0: bake scene parameters into the program')
@@ -52,6 +55,10 @@ def parse_args():
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
     return ap.parse_args()
+
+
+def tiles_requested(args, world):
+    return args.partition == 'tiles' and world > 1
 
 
 def stripe(tape, rank, world):
@@ -132,10 +139,14 @@ def main():
         ray_range = (first, max(min(per_rank, width * height - first), 256))
     hint = int(args.occupancy_hint) if args.occupancy_hint.isdigit() else None
     r = Renderer(scene, seed=args.seed, device_index=local_rank, ray_range=ray_range,
-                 min_waves_per_simd=hint,
+                 min_waves_per_simd=hint, rng_mode=args.rng,
                  build_options=args.build_options.split() if args.build_options else None,
                  bake_parameters=None if args.bake is None else bool(args.bake))
-    r.regenerate = bool(args.regenerate)
+    if args.regenerate is not None:
+        r.regenerate = bool(args.regenerate)
+    if args.rng == 'philox' and not tiles_requested(args, world):
+        # pass-striped ranks count their passes locally: give every rank its own streams
+        r.rng_seed ^= (rank * 0xD1342543DE82EF95) & (2**64 - 1)
     if args.occupancy_hint == 'auto':
         r.tune_occupancy()                      # part of the program build, outside the timed region
         if rank == 0:
@@ -187,8 +198,10 @@ def main():
         'scaling': 'strong' if tiles else 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s %dx%d, %d sample passes per step (%s, next-event light, '
-                               'max_bounces %d), broadcast random tape, build options %s'
+                               'max_bounces %d), %s, build options %s'
                                % (args.scene, width, height, P, 'RGB' if r.shader.rgb else 'spectral', scene.max_bounces,
+                                  'broadcast random tape' if args.rng == 'tape' else
+                                  'per-pixel Philox random numbers' + (', path regeneration' if r.regenerate else ''),
                                   ' '.join(r.build_options)),
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'speculative_exact_arithmetic': bool(r.speculate),
