@@ -32,6 +32,9 @@ def main():
     ap.add_argument('--seed', type=int, default=None)
     ap.add_argument('--device', type=int, default=0)
     ap.add_argument('--batch', type=int, default=None, help='passes per kernel launch')
+    ap.add_argument('--rng', choices=['tape', 'philox'], default='tape',
+                    help="tape: the reference's random numbers, shared by all pixels of a pass; "
+                         "philox: every pixel draws its own (less correlated noise)")
     ap.add_argument('scene')
     args = ap.parse_args()
 
@@ -48,7 +51,7 @@ def main():
         scene.samples_per_pixel = args.spp
 
     image = Image(RAW_OUTPUT_FILE if args.append else None, settings=scene.image)
-    renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device)
+    renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device, rng_mode=args.rng)
     if scene.samples_per_pixel >= 64:
         renderer.tune_occupancy(passes=8)       # pays off for long renders only
     acc = renderer.acc
