@@ -119,7 +119,9 @@ def get_binary(source, options, arch):
     if use_child:
         try:
             binary, how = compile_in_child(source, options, arch), 'child'
-        except OSError:          # no child processes here: compile with what this process has
+        except (OSError, accelerator.ClrError):
+            # no child processes here (some profilers and sandboxes refuse them), or the source
+            # does not compile: compile with what this process has, which reports the latter
             binary, how = compile_here(source, options, arch), 'here'
     else:
         binary, how = compile_here(source, options, arch), 'here'
