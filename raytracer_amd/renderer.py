@@ -49,7 +49,7 @@ class Renderer:
         self._init_camera_and_image()
         self._init_materials()
 
-        # exact division / square root by operand-range speculation with per-segment replay
+        # exact division / square root by operand-range speculation with path restart
         # (hip_templates/clr_exact.inl); False = the compiler's generic expansions everywhere
         # default: on when every shape of the scene is a quadric / convex body - their steps are
         # dominated by the divisions and square roots of the ray set-up.  Marching and mesh
