@@ -86,27 +86,44 @@ CLR_MATH_FN void clr_normal_pair(float u1, float u2, float *g0, float *g1) {
  *   block 0: direction on the sphere (2), stage sample p, Russian-roulette sample
  *   block 1: gaussian vector (3 of 4 normals)
  *   block 2: light choice, point on the light (2)          - only with next-event lights
- * out: rvec[3], p, gauss[3], russian, light_u (choice), light_dir[3] */
+ * The blocks are independent functions of the counter, so a caller may evaluate only the ones
+ * it consumes (the device code draws blocks 1 and 2 where they are used) and still sees the
+ * numbers of clr_draw_segment, which evaluates all of them. */
 typedef struct clr_segment_draw {
     float rvec[3], p, gauss[3], russian, light_u, light_dir[3];
 } clr_segment_draw;
 
-CLR_MATH_FN void clr_draw_segment(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
-                                  unsigned segment, int with_light, clr_segment_draw *d) {
+CLR_MATH_FN void clr_draw_block0(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
+                                 unsigned segment, float rvec[3], float *p, float *russian) {
+    unsigned r[4];
+    clr_philox4x32(pixel, pass, segment, 0u, seed_lo, seed_hi, r);
+    clr_sphere_direction(clr_u01(r[0]), clr_u01(r[1]), rvec);
+    *p = clr_u01(r[2]);
+    *russian = clr_u01(r[3]);
+}
+
+CLR_MATH_FN void clr_draw_gauss(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
+                                unsigned segment, float gauss[3]) {
     unsigned r[4];
     float unused;
-    clr_philox4x32(pixel, pass, segment, 0u, seed_lo, seed_hi, r);
-    clr_sphere_direction(clr_u01(r[0]), clr_u01(r[1]), d->rvec);
-    d->p = clr_u01(r[2]);
-    d->russian = clr_u01(r[3]);
     clr_philox4x32(pixel, pass, segment, 1u, seed_lo, seed_hi, r);
-    clr_normal_pair(clr_u01(r[0]), clr_u01(r[1]), &d->gauss[0], &d->gauss[1]);
-    clr_normal_pair(clr_u01(r[2]), clr_u01(r[3]), &d->gauss[2], &unused);
+    clr_normal_pair(clr_u01(r[0]), clr_u01(r[1]), &gauss[0], &gauss[1]);
+    clr_normal_pair(clr_u01(r[2]), clr_u01(r[3]), &gauss[2], &unused);
+}
+
+CLR_MATH_FN void clr_draw_light(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
+                                unsigned segment, float *light_u, float light_dir[3]) {
+    unsigned r[4];
+    clr_philox4x32(pixel, pass, segment, 2u, seed_lo, seed_hi, r);
+    *light_u = clr_u01(r[0]);
+    clr_sphere_direction(clr_u01(r[1]), clr_u01(r[2]), light_dir);
+}
+
+CLR_MATH_FN void clr_draw_segment(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
+                                  unsigned segment, int with_light, clr_segment_draw *d) {
+    clr_draw_block0(seed_lo, seed_hi, pixel, pass, segment, d->rvec, &d->p, &d->russian);
+    clr_draw_gauss(seed_lo, seed_hi, pixel, pass, segment, d->gauss);
     d->light_u = 0.0f;
     d->light_dir[0] = d->light_dir[1] = 0.0f; d->light_dir[2] = 1.0f;
-    if (with_light) {
-        clr_philox4x32(pixel, pass, segment, 2u, seed_lo, seed_hi, r);
-        d->light_u = clr_u01(r[0]);
-        clr_sphere_direction(clr_u01(r[1]), clr_u01(r[2]), d->light_dir);
-    }
+    if (with_light) clr_draw_light(seed_lo, seed_hi, pixel, pass, segment, &d->light_u, d->light_dir);
 }

@@ -135,7 +135,10 @@ CLR_FN BounceSample clr_load_bounce(const float4 * __restrict__ rec) {
     BounceSample B;
     const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3], e = rec[4];
     B.rvec = make_vec3(a); B.p = a.w;
-    B.gauss = make_vec3(b); B.russian = b.w;
+### if renderer.rng_mode != 'philox'
+    B.gauss = make_vec3(b);
+### endif
+    B.russian = b.w;
     B.light_point = make_vec3(c); B.light_area = c.w;
     B.light_normal = make_vec3(d); B.min_light_sampling_distance = d.w;
     B.light_center = make_vec3(e); B.light_id = __float_as_int(e.w);
@@ -143,27 +146,32 @@ CLR_FN BounceSample clr_load_bounce(const float4 * __restrict__ rec) {
 }
 
 ### if renderer.rng_mode == 'philox'
-// the record of one segment from the pixel's own stream (same fields as the tape record)
+// the record of one segment from the pixel's own stream (same fields as the tape record); the
+// light sample is drawn only where the segment can use it, the gaussian vector inside clr_shade
 CLR_FN BounceSample clr_draw_bounce(const uint seed_lo, const uint seed_hi, const uint pixel,
-                                    const uint pass, const uint segment, const bool is_last) {
+                                    const uint pass, const uint segment, const bool with_light) {
     BounceSample B;
-    clr_segment_draw d;
-    clr_draw_segment(seed_lo, seed_hi, pixel, pass, segment, {{ 1 if renderer.n_lights else 0 }}, &d);
-    B.rvec = make_vec3(d.rvec[0], d.rvec[1], d.rvec[2]); B.p = d.p;
-    B.gauss = make_vec3(d.gauss[0], d.gauss[1], d.gauss[2]); B.russian = d.russian;
+    float rvec[3];
+    clr_draw_block0(seed_lo, seed_hi, pixel, pass, segment, rvec, &B.p, &B.russian);
+    B.rvec = make_vec3(rvec[0], rvec[1], rvec[2]);
+    B.seed_lo = seed_lo; B.seed_hi = seed_hi; B.pixel = pixel; B.pass = pass; B.segment = segment;
     B.light_point = make_vec3(0.0f, 0.0f, 0.0f); B.light_area = 0.0f;
     B.light_normal = make_vec3(0.0f, 0.0f, 0.0f); B.min_light_sampling_distance = 0.0f;
     B.light_center = make_vec3(0.0f, 0.0f, 0.0f); B.light_id = 0;
     ### if renderer.n_lights
-    int idx = (int)(d.light_u * {{ renderer.n_lights|float }}f);
-    if (idx > {{ renderer.n_lights - 1 }}) idx = {{ renderer.n_lights - 1 }};
-    const float4 L0 = clr_lights[2*idx], L1 = clr_lights[2*idx + 1];
-    B.light_normal = make_vec3(d.light_dir[0], d.light_dir[1], d.light_dir[2]);
-    B.light_point = make_vec3(L0.x + d.light_dir[0] * L0.w, L0.y + d.light_dir[1] * L0.w, L0.z + d.light_dir[2] * L0.w);
-    B.light_area = L1.x;
-    B.min_light_sampling_distance = L1.y;
-    B.light_center = make_vec3(L0);
-    if (!is_last) B.light_id = __float_as_int(L1.z);
+    if (with_light) {
+        float light_u, light_dir[3];
+        clr_draw_light(seed_lo, seed_hi, pixel, pass, segment, &light_u, light_dir);
+        int idx = (int)(light_u * {{ renderer.n_lights|float }}f);
+        if (idx > {{ renderer.n_lights - 1 }}) idx = {{ renderer.n_lights - 1 }};
+        const float4 L0 = clr_lights[2*idx], L1 = clr_lights[2*idx + 1];
+        B.light_normal = make_vec3(light_dir[0], light_dir[1], light_dir[2]);
+        B.light_point = make_vec3(L0.x + light_dir[0] * L0.w, L0.y + light_dir[1] * L0.w, L0.z + light_dir[2] * L0.w);
+        B.light_area = L1.x;
+        B.min_light_sampling_distance = L1.y;
+        B.light_center = make_vec3(L0);
+        B.light_id = __float_as_int(L1.z);
+    }
     ### endif
     return B;
 }
@@ -300,8 +308,11 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
         if (active) {
             const bool is_last = segment == CLR_MAX_BOUNCES - 1;
 ### if renderer.rng_mode == 'philox'
+            // the light sample feeds the visibility test and the diffuse stage, both of which
+            // need a diffuse bounce to be left and are skipped on the last segment
             const BounceSample B = clr_draw_bounce(rng_seed_lo, rng_seed_hi, (uint)(first_ray + k),
-                                                   (uint)(first_pass + pass), (uint)segment, is_last);
+                                                   (uint)(first_pass + pass), (uint)segment,
+                                                   !is_last && s.diffusions_left > 0);
 ### else
             const BounceSample B = clr_load_bounce(bounce_tape + ((size_t)pass * CLR_MAX_BOUNCES + segment) * CLR_BOUNCE_STRIDE);
 ### endif

@@ -38,7 +38,19 @@ struct PathState {
 
 struct BounceSample {                    // one record of the random tape
     vec3 rvec; float p;                  // unit vector, stage sample
-    vec3 gauss; float russian;           // gaussian vector, Russian-roulette sample
+    float russian;                       // Russian-roulette sample
+### if renderer.rng_mode == 'philox'
+    // the gaussian vector is block 1 of the pixel's stream: drawn where a blurred stage uses it
+    uint seed_lo, seed_hi, pixel, pass, segment;
+    CLR_FN_MEMBER vec3 gauss_vector() const {
+        float g[3];
+        clr_draw_gauss(seed_lo, seed_hi, pixel, pass, segment, g);
+        return make_vec3(g[0], g[1], g[2]);
+    }
+### else
+    vec3 gauss;                          // gaussian vector
+    CLR_FN_MEMBER vec3 gauss_vector() const { return gauss; }
+### endif
     vec3 light_point; float light_area;
     vec3 light_normal; float min_light_sampling_distance;
     vec3 light_center; int light_id;     // 0 on the last segment / without lights
@@ -56,7 +68,6 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 {
     float p = B.p;
     vec3 r = s.ray;
-    vec3 gauss_rvec = B.gauss;
     float cur_prob = 0.0f;
     color_t cur_col;
     color_t pipeline_color;
@@ -74,7 +85,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
             last_dist = d;
             s.whichobject = 0;
             const float blur = SCALAR(MAT_VOLUME_SCATTERING_BLUR, s.inside);
-            if (blur < 1.0f) r = normalize(gauss_rvec + r * clr_tanf(CLR_PI_F*0.5f*(1.0f - blur)));
+            if (blur < 1.0f) r = normalize(B.gauss_vector() + r * clr_tanf(CLR_PI_F*0.5f*(1.0f - blur)));
             else r = B.rvec;
 ### if renderer.bidirectional
             s.suppress_emission = 0;
@@ -116,6 +127,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
             r -= 2*dot(r, n) * n;
             const float blur = SCALAR(MAT_REFLECTION_BLUR, s.whichobject);
             if (blur > 0) {
+                vec3 gauss_rvec = B.gauss_vector();
                 if (dot(n, gauss_rvec) < 0) gauss_rvec = -gauss_rvec;
                 r = normalize(gauss_rvec * blur + r * (1.0f - blur));
             }
@@ -165,6 +177,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
             if (dot(n, r) < 0) n = -n;
             const float blur = SCALAR(MAT_TRANSPARENCY_BLUR, s.whichobject);
             if (blur > 0) {
+                vec3 gauss_rvec = B.gauss_vector();
                 if (dot(n, gauss_rvec) < 0) gauss_rvec = -gauss_rvec;
                 r = normalize(gauss_rvec * blur + r * (1.0f - blur));
             }
