@@ -1001,7 +1001,7 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
                int n_threads, double *flops, const orc_rng *rng) {
     const int stride = sc->n_objects + 1;
     const int row_len = 10 * stride;
-    double total_flops = 0.0;
+    double total_flops = 0.0, total_bytes = 0.0;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
@@ -1037,6 +1037,8 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
     }
 #ifdef ORC_COUNT_FLOPS
     orc_mesh_bytes_total = total_bytes;
+#else
+    (void)total_bytes;
 #endif
     if (flops) *flops = total_flops;
     return 0;
