@@ -20,6 +20,12 @@ __constant__ int clr_data_offsets[{{ [2*n_objects, 2]|max }}];              // p
 ### if shader.rgb
 __constant__ float4 clr_material_colors[{{ 5*(n_objects+1) }}];
 __constant__ float clr_material_scalars[{{ 5*(n_objects+1) }}];
+### if renderer.materials_in_lds
+// block-local copy: a stage reads the properties of the surface it is on by object id, one
+// dependent gather per stage; from LDS that is ~60 cycles each instead of a trip to L2
+static __shared__ float4 clr_lds_material_colors[{{ 5*(n_objects+1) }}];
+static __shared__ float clr_lds_material_scalars[{{ 5*(n_objects+1) }}];
+### endif
 ### endif
 
 // 1: every pixel draws its own random numbers (clr_rng.inl), 0: they come from the bounce tape;
@@ -279,6 +285,13 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
     const int kk = in_image ? k : 0;
     const vec3 base_ray = make_vec3(cam[kk]);
     const float4 img0 = img[kk];
+### if shader.rgb and renderer.materials_in_lds
+    for (int i = threadIdx.x; i < {{ 5*(n_objects+1) }}; i += blockDim.x) {
+        clr_lds_material_colors[i] = clr_material_colors[i];
+        clr_lds_material_scalars[i] = clr_material_scalars[i];
+    }
+    __syncthreads();
+### endif
     vec3 acc = make_vec3(img0.x, img0.y, img0.z);
 
     PathState s;

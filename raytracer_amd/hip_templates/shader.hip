@@ -11,9 +11,14 @@
 
 ### if shader.rgb
 typedef vec3 color_t;
+### if renderer.materials_in_lds
+#define COLOR(prop, id) make_vec3(clr_lds_material_colors[(prop) + (id)])
+#define SCALAR(prop, id) clr_lds_material_scalars[(prop) + (id)]
+### else
 #define COLOR(prop, id) make_vec3(clr_material_colors[(prop) + (id)])
-#define COLOR2PROB(color) (dot(color, make_vec3(1.0f, 1.0f, 1.0f))/3.0f)
 #define SCALAR(prop, id) clr_material_scalars[(prop) + (id)]
+### endif
+#define COLOR2PROB(color) (dot(color, make_vec3(1.0f, 1.0f, 1.0f))/3.0f)
 #define COLOR_ONE make_vec3(1.0f, 1.0f, 1.0f)
 CLR_FN vec3 color_to_rgb(vec3 c, vec3 cmask) { return c; }
 ### else

@@ -81,6 +81,10 @@ template<class CLR_G> CLR_FN void {{ obj.tracer_kernel_name }}(
 
         const vec3 local_pos = clr_to_local_position(p_inverse_affine, pos, affine_skip, clr_g);
         const vec3 local_ray = clr_to_local_direction(p_inverse_affine, ray, affine_skip, clr_g);
+    ### if obj.can_hit_expression
+        // sign test of the class: where it fails the ray test below is known to report no hit
+        if ({{ obj.can_hit_expression }}) {
+    ### endif
         // unit direction, stretch = |local_ray|; the four quotients by stretch share one reciprocal
         const clr_direction dir = clr_make_direction(local_ray, clr_g);
 
@@ -100,6 +104,9 @@ template<class CLR_G> CLR_FN void {{ obj.tracer_kernel_name }}(
                 whichobject = object_id;
             }
         }
+    ### if obj.can_hit_expression
+        }
+    ### endif
     ### if obj.convex
     }
     ### endif
@@ -125,6 +132,10 @@ template<class CLR_G> CLR_FN void {{ obj.shadow_kernel_name }}(
         const float4 *p_inverse_affine = P + {{ obj.parameter_types()|length }};
         const vec3 local_pos = clr_to_local_position(p_inverse_affine, pos, affine_skip, clr_g);
         const vec3 local_ray = clr_to_local_direction(p_inverse_affine, ray, affine_skip, clr_g);
+    ### if obj.can_hit_expression
+        // sign test of the class: where it fails the ray test below is known to report no hit
+        if ({{ obj.can_hit_expression }}) {
+    ### endif
         // unit direction, stretch = |local_ray|; the four quotients by stretch share one reciprocal
         const clr_direction dir = clr_make_direction(local_ray, clr_g);
 
@@ -140,6 +151,9 @@ template<class CLR_G> CLR_FN void {{ obj.shadow_kernel_name }}(
             new_isec_dist = clr_over_length(new_isec_dist, dir, clr_g);
             if (new_isec_dist < isec_dist) shadow_mask = 0.0f;
         }
+    ### if obj.can_hit_expression
+        }
+    ### endif
     ### if obj.convex
     }
     ### endif

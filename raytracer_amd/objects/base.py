@@ -63,6 +63,12 @@ class Tracer(object):
     # the speculative exact arithmetic of hip_templates/clr_exact.inl for the scene
     speculation_friendly = False
 
+    # Optional HIP expression over `local_pos` and `local_ray` (tracer coordinates, ray not yet
+    # normalised).  Where it is false the class's ray test is KNOWN to report no hit, and the
+    # step functions skip the normalisation and the test.  It must be exact: false only if the
+    # full IEEE evaluation also ends without a hit (true is always allowed).
+    can_hit_expression = None
+
     def __init__(self, position=(0, 0, 0), **affine_kwargs):
         # non-empty => one generated function per instance instead of one per class
         self.unique_tracer_id = ""

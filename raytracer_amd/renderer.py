@@ -96,6 +96,9 @@ class Renderer:
                                         if obj.bidirectional_light]
         self.bidirectional = len(self.bidirectional_light_ids) > 0
         self.n_lights = len(self.bidirectional_light_ids)
+        # RGB material tables (5 float4 + 5 float per object and the ambient medium) are copied to
+        # LDS by every block when they are small: 10 kB at most
+        self.materials_in_lds = bool(self.shader.rgb) and 5 * (len(self.scene.objects) + 1) <= 512
         # per-pixel random numbers: the light points are drawn on the device, from this table
         # (centre, R, area, minimum sampling distance, object id); spheres only
         self.light_table = np.zeros((self.n_lights, 8), dtype=np.float32)

@@ -20,16 +20,21 @@ SRC = os.path.join(ROOT, 'gpurun_out', 'prof')
 DST = os.path.join(ROOT, 'profiles')
 
 
+def newest(pattern):
+    """gpurun merges every call's output into the same directories: take the latest run's file."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def main(tag, key):
     os.makedirs(DST, exist_ok=True)
-    stats = glob.glob(os.path.join(SRC, 'trace', '*', '*_kernel_stats.csv'))[0]
+    stats = newest(os.path.join(SRC, 'trace', '*', '*_kernel_stats.csv'))
     shutil.copy(stats, os.path.join(DST, tag + '_kernel_stats.csv'))
-    trace = glob.glob(os.path.join(SRC, 'trace', '*', '*_kernel_trace.csv'))[0]
+    trace = newest(os.path.join(SRC, 'trace', '*', '*_kernel_trace.csv'))
     rows = [r for r in csv.DictReader(open(trace)) if r['Kernel_Name'] == 'clr_render']
     durations = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
     counters = collections.OrderedDict()
     for d in ('pmc_sq', 'pmc_fetch', 'pmc_write', 'pmc_grbm'):
-        for f in glob.glob(os.path.join(SRC, d, '*', '*_counter_collection.csv')):
+        for f in [newest(os.path.join(SRC, d, '*', '*_counter_collection.csv'))]:
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 if r['Kernel_Name'] == 'clr_render':
