@@ -90,11 +90,24 @@ CLR_FN vec3 clr_surface_normal(const vec3 pos, const vec3 ray, const uint whicho
     const uint which_subobject, const uint inside,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data)
 {
+### if renderer.bake_parameters and n_objects <= 24
+    // one case per object: its parameters are literals, so e.g. the normal of a wall is a constant,
+    // and a wave runs only the cases of the objects its lanes are on (no gather from the table)
+### for tracer, count, offset in renderer.object_groups
+### set group = loop.index0
+    ### for i in range(count)
+    if (whichobject == {{ offset+1+i }})
+        return {{ tracer.normal_kernel_name }}(pos, ray, which_subobject, inside, vector_data, integer_data,
+            {{ offset+1+i }}, clr_params + {{ renderer.group_param_base[group] + i*renderer.group_param_stride[group] }});
+    ### endfor
+### endfor
+### else
 ### for tracer, count, offset in renderer.object_groups
     {% if not loop.first %}else {% endif %}if (whichobject >= {{ offset+1 }} && whichobject < {{ offset+1+count }})
         return {{ tracer.normal_kernel_name }}(pos, ray, which_subobject, inside, vector_data, integer_data,
             (int)whichobject, clr_params + {{ renderer.group_param_base[loop.index0] }} + (whichobject - {{ offset+1 }})*{{ renderer.group_param_stride[loop.index0] }});
 ### endfor
+### endif
     return make_vec3(0.0f, 0.0f, 0.0f);
 }
 
