@@ -77,10 +77,44 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
     color_t cur_col;
     color_t pipeline_color;
 
+### if renderer.materials_in_lds
+    // properties of the medium and of the surface: looked up in LDS where a stage needs them
+    #define m_scattering SCALAR(MAT_VOLUME_SCATTERING, s.inside)
+    #define m_scattering_blur SCALAR(MAT_VOLUME_SCATTERING_BLUR, s.inside)
+    #define m_absorption COLOR(MAT_VOLUME_ABSORPTION, s.inside)
+    #define m_emission COLOR(MAT_EMISSION, s.whichobject)
+    #define m_reflection COLOR(MAT_REFLECTION, s.whichobject)
+    #define m_transparency COLOR(MAT_TRANSPARENCY, s.whichobject)
+    #define m_diffuse COLOR(MAT_DIFFUSE, s.whichobject)
+    #define m_reflection_blur SCALAR(MAT_REFLECTION_BLUR, s.whichobject)
+    #define m_transparency_blur SCALAR(MAT_TRANSPARENCY_BLUR, s.whichobject)
+    #define m_ior SCALAR(MAT_IOR, s.whichobject)
+    #define m_ior_ambient SCALAR(MAT_IOR, 0)
+    #define m_light_emission COLOR(MAT_EMISSION, B.light_id)
+### else
+    // Properties of the medium and of the surface come from global memory here: fetched together
+    // up front, because inside the stages they would be one dependent look-up after another (the
+    // stages are sequential by construction; with the tables in LDS that costs less than the
+    // registers do).  No stage changes s.whichobject or s.inside before it has used them.
+    const float m_scattering = SCALAR(MAT_VOLUME_SCATTERING, s.inside);
+    const float m_scattering_blur = SCALAR(MAT_VOLUME_SCATTERING_BLUR, s.inside);
+    const color_t m_absorption = COLOR(MAT_VOLUME_ABSORPTION, s.inside);
+    const color_t m_emission = COLOR(MAT_EMISSION, s.whichobject);
+    const color_t m_reflection = COLOR(MAT_REFLECTION, s.whichobject);
+    const color_t m_transparency = COLOR(MAT_TRANSPARENCY, s.whichobject);
+    const color_t m_diffuse = COLOR(MAT_DIFFUSE, s.whichobject);
+    const float m_reflection_blur = SCALAR(MAT_REFLECTION_BLUR, s.whichobject);
+    const float m_transparency_blur = SCALAR(MAT_TRANSPARENCY_BLUR, s.whichobject);
+    const float m_ior = SCALAR(MAT_IOR, s.whichobject), m_ior_ambient = SCALAR(MAT_IOR, 0);
+    ### if renderer.bidirectional
+    const color_t m_light_emission = COLOR(MAT_EMISSION, B.light_id);     // id 0: the ambient entry
+    ### endif
+### endif
+
     // ---- volumetric effects (shader.cl:124-170)
     {
         float last_dist = last_distance;
-        const float alpha = SCALAR(MAT_VOLUME_SCATTERING, s.inside);
+        const float alpha = m_scattering;
         if (alpha > 0) cur_prob = 1.0f - clr_expf(-alpha*last_dist);
 
         if (p < cur_prob) {
@@ -89,7 +123,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
             s.pos -= (last_dist - d) * r;
             last_dist = d;
             s.whichobject = 0;
-            const float blur = SCALAR(MAT_VOLUME_SCATTERING_BLUR, s.inside);
+            const float blur = m_scattering_blur;
             if (blur < 1.0f) r = normalize(B.gauss_vector() + r * clr_tanf(CLR_PI_F*0.5f*(1.0f - blur)));
             else r = B.rvec;
 ### if renderer.bidirectional
@@ -100,10 +134,10 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
         else p -= cur_prob;
 
 ### if shader.rgb
-        cur_col = COLOR(MAT_VOLUME_ABSORPTION, s.inside);
+        cur_col = m_absorption;
         pipeline_color = make_vec3(clr_expf(-cur_col.x*last_dist), clr_expf(-cur_col.y*last_dist), clr_expf(-cur_col.z*last_dist));
 ### else
-        pipeline_color = clr_expf(-SCALAR(MAT_VOLUME_ABSORPTION, s.inside)*last_dist);
+        pipeline_color = clr_expf(-m_absorption*last_dist);
 ### endif
         if (p < 0.0f) { s.ray = r; s.ray_color = s.ray_color * pipeline_color; }
     }
@@ -115,7 +149,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
         if ((suppressed >= 0 && s.whichobject != (uint)suppressed) || s.whichobject == (uint)(-suppressed))
 ### endif
         {
-            img += color_to_rgb(COLOR(MAT_EMISSION, s.whichobject) * s.ray_color * pipeline_color, cmask);
+            img += color_to_rgb(m_emission * s.ray_color * pipeline_color, cmask);
         }
     }
 
@@ -123,14 +157,14 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 
     // ---- specular reflection (shader.cl:190-217)
     if (p >= 0.0f) {
-        cur_col = COLOR(MAT_REFLECTION, s.whichobject);
+        cur_col = m_reflection;
         cur_prob = COLOR2PROB(cur_col);
         if (p < cur_prob) {
 ### if shader.rgb
             pipeline_color *= cur_col / cur_prob;
 ### endif
             r -= 2*dot(r, n) * n;
-            const float blur = SCALAR(MAT_REFLECTION_BLUR, s.whichobject);
+            const float blur = m_reflection_blur;
             if (blur > 0) {
                 vec3 gauss_rvec = B.gauss_vector();
                 if (dot(n, gauss_rvec) < 0) gauss_rvec = -gauss_rvec;
@@ -147,7 +181,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 
     // ---- refraction / transparency (shader.cl:219-288)
     if (p >= 0.0f) {
-        cur_col = COLOR(MAT_TRANSPARENCY, s.whichobject);
+        cur_col = m_transparency;
         cur_prob = COLOR2PROB(cur_col);
         if (p < cur_prob) {
 ### if shader.rgb
@@ -157,8 +191,8 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
             if (dotp > 0) { n = -n; dotp = -dotp; }
 
             float nfrac = 0;
-            const float ior1 = SCALAR(MAT_IOR, s.whichobject);
-            const float ior0 = SCALAR(MAT_IOR, 0);
+            const float ior1 = m_ior;
+            const float ior0 = m_ior_ambient;
             if (s.inside == s.whichobject) {         // leaving the object
                 nfrac = ior1/ior0;
                 s.inside = 0;
@@ -180,7 +214,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
             }
 
             if (dot(n, r) < 0) n = -n;
-            const float blur = SCALAR(MAT_TRANSPARENCY_BLUR, s.whichobject);
+            const float blur = m_transparency_blur;
             if (blur > 0) {
                 vec3 gauss_rvec = B.gauss_vector();
                 if (dot(n, gauss_rvec) < 0) gauss_rvec = -gauss_rvec;
@@ -200,7 +234,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 ### if renderer.bidirectional
         s.suppress_emission = 0;
 ### endif
-        cur_col = COLOR(MAT_DIFFUSE, s.whichobject);
+        cur_col = m_diffuse;
         cur_prob = COLOR2PROB(cur_col);
 
         if (cur_prob > 0.0f && s.diffusions_left > 0) {
@@ -218,7 +252,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
                         const float geom = dot(n, shadow_ray) / CLR_PI_F
                             * dot(-shadow_ray, B.light_normal) / (shadow_dist*shadow_dist);
                         img += color_to_rgb(geom * s.ray_color * pipeline_color, cmask)
-                            * color_to_rgb(COLOR(MAT_EMISSION, B.light_id), make_vec3(1.0f, 1.0f, 1.0f))
+                            * color_to_rgb(m_light_emission, make_vec3(1.0f, 1.0f, 1.0f))
                             * shadow_mask * B.light_area;
                     }
                 }
@@ -257,3 +291,8 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
     }
     return true;
 }
+### if renderer.materials_in_lds
+### for name in ['scattering', 'scattering_blur', 'absorption', 'emission', 'reflection', 'transparency', 'diffuse', 'reflection_blur', 'transparency_blur', 'ior', 'ior_ambient', 'light_emission']
+#undef m_{{ name }}
+### endfor
+### endif

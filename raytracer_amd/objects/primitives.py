@@ -48,8 +48,9 @@ class HalfSpace(Tracer):
     # the sign of a quotient is exact, a zero or NaN operand gives a zero, an infinity (never below
     # the current distance) or a NaN.  About half of the walls of a room drop out this way, and
     # neighbouring rays agree on which, so whole waves skip the test.
-    can_hit_expression = ('(local_pos.x > 0.0f && local_ray.x < 0.0f) || '
-                          '(local_pos.x < 0.0f && local_ray.x > 0.0f)')
+    # (bitwise operators: four compares and three mask operations, no short-circuit branches)
+    can_hit_expression = ('((local_pos.x > 0.0f) & (local_ray.x < 0.0f)) | '
+                          '((local_pos.x < 0.0f) & (local_ray.x > 0.0f))')
 
     def __init__(self, normal, h):
         Tracer.__init__(self)
