@@ -11,8 +11,9 @@
 //     exponent(a) - exponent(d) < 96  and the quotient is not denormal,
 // all of which hold for 2^-47 <= |a|, |d| <= 2^47.  What remains is the FMA chain below: its
 // first half depends on the divisor only and is shared by all quotients with that divisor
-// (ray / |ray| and t / |ray| of every object test), and two quotients at a time go through
-// packed FP32 instructions.
+// (ray / |ray| and t / |ray| of every object test).  Scalar instructions throughout: packed FP32
+// (v_pk_fma_f32) was measured slower here, written by hand or made by the SLP vectoriser (the
+// register pairs cost moves and registers; programs are built with -fno-slp-vectorize).
 // Square root.  v_sqrt_f32 is within 1 ulp; its two neighbours are tested with one FMA residual
 // each, as in the generic expansion, whose input scaling, un-scaling and class test matter only
 // below 2^-96.
@@ -29,8 +30,6 @@
 // and the range is lo >= 2^-94, hi <= 2^30.  Then components are >= 2^-47 and lengths are in
 // [2^-47, 2^30], so quotients component / length and t / length are normal numbers with an
 // exponent difference < 96 and numerators >= 2^-103, and sqrt arguments are in [2^-94, 2^60].
-typedef float clr_f2 __attribute__((ext_vector_type(2)));
-
 #ifndef CLR_GUARD_LO
 #define CLR_GUARD_LO 0x1p-94f
 #endif
@@ -78,15 +77,6 @@ CLR_FN float clr_quotient_short(float a, float d, float y) {
     return __builtin_fmaf(r, y, q);
 }
 
-CLR_FN clr_f2 clr_quotient_short(clr_f2 a, float d, float y) {
-    const clr_f2 dd = {-d, -d}, yy = {y, y};
-    clr_f2 q = a * yy;
-    clr_f2 r = __builtin_elementwise_fma(dd, q, a);
-    q = __builtin_elementwise_fma(r, yy, q);
-    r = __builtin_elementwise_fma(dd, q, a);
-    return __builtin_elementwise_fma(r, yy, q);
-}
-
 // ---- square root
 CLR_FN float clr_sqrt(float x, const clr_guard_safe &) { return sqrtf(x); }
 CLR_FN float clr_sqrt(float x, clr_guard_spec &g) {
@@ -116,8 +106,8 @@ CLR_FN clr_direction clr_make_direction(vec3 v, clr_guard_spec &g) {
     const float xx = v.x * v.x, yy = v.y * v.y, zz = v.z * v.z;
     r.len = clr_sqrt_short(xx + yy + zz);
     r.y = clr_reciprocal_short(r.len);
-    const clr_f2 xy = clr_quotient_short((clr_f2){v.x, v.y}, r.len, r.y);
-    r.unit = make_vec3(xy.x, xy.y, clr_quotient_short(v.z, r.len, r.y));
+    r.unit = make_vec3(clr_quotient_short(v.x, r.len, r.y), clr_quotient_short(v.y, r.len, r.y),
+                       clr_quotient_short(v.z, r.len, r.y));
     g.lo = CLR_IMIN(CLR_IMIN(g.lo, CLR_BITS(xx)), CLR_BITS(yy));
     g.lo = CLR_IMIN(g.lo, CLR_BITS(zz));
     return r;

@@ -22,15 +22,36 @@ SETS = {
         'speculative': (BASE, {'speculate': True}),
         'replay-heavy': (BASE + ['-DCLR_GUARD_LO=0x1p-7f'], {'speculate': True}),
     },
+    # code generation only (all bit-identical): SLP packing, scheduler strategy, machine LICM
+    'codegen': {
+        'parity': (BASE, {'min_waves_per_simd': 5}),
+        'noslp5': (BASE + ['-fno-slp-vectorize'], {'min_waves_per_simd': 5}),
+        'noslp4': (BASE + ['-fno-slp-vectorize'], {'min_waves_per_simd': 4}),
+        'noslp6': (BASE + ['-fno-slp-vectorize'], {'min_waves_per_simd': 6}),
+        'maxilp5': (BASE + ['-mllvm', '-amdgpu-sched-strategy=max-ilp'], {'min_waves_per_simd': 5}),
+        'nomlicm5': (BASE + ['-mllvm', '-disable-machine-licm'], {'min_waves_per_simd': 5}),
+        'noslp+ilp5': (BASE + ['-fno-slp-vectorize', '-mllvm', '-amdgpu-sched-strategy=max-ilp'], {'min_waves_per_simd': 5}),
+        'noslp+nomlicm5': (BASE + ['-fno-slp-vectorize', '-mllvm', '-disable-machine-licm'], {'min_waves_per_simd': 5}),
+    },
+    'codegen2': {
+        'parity': (BASE, {}),
+        'noslp': (BASE + ['-fno-slp-vectorize'], {}),
+        'noslp+nomlicm': (BASE + ['-fno-slp-vectorize', '-mllvm', '-disable-machine-licm'], {}),
+        'noslp+scalarq': (BASE + ['-fno-slp-vectorize', '-DCLR_SCALAR_QUOTIENTS'], {}),
+        'noslp+scalarq5': (BASE + ['-fno-slp-vectorize', '-DCLR_SCALAR_QUOTIENTS'], {'min_waves_per_simd': 5}),
+        'noslp+scalarq6': (BASE + ['-fno-slp-vectorize', '-DCLR_SCALAR_QUOTIENTS'], {'min_waves_per_simd': 6}),
+    },
 }
 
 
 def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
+    passes = int(os.environ.get('PASSES', passes))
     rs = {}
     tape = None
     for name, opts in VARIANTS.items():
-        scene = runpy.run_path('raytracer_amd/scenes/%s.py' % scene_name)['scene']
-        scene.image.size = size
+        sys.path.insert(0, 'tests')
+        from conftest import load_scene
+        scene = load_scene(scene_name, size)
         kwargs = {}
         if isinstance(opts, tuple):
             opts, kwargs = opts
