@@ -41,6 +41,14 @@ SETS = {
         'noslp+scalarq5': (BASE + ['-fno-slp-vectorize', '-DCLR_SCALAR_QUOTIENTS'], {'min_waves_per_simd': 5}),
         'noslp+scalarq6': (BASE + ['-fno-slp-vectorize', '-DCLR_SCALAR_QUOTIENTS'], {'min_waves_per_simd': 6}),
     },
+    'codegen3': {
+        'parity': (BASE + ['-fno-slp-vectorize'], {}),
+        'nopostsched': (BASE + ['-fno-slp-vectorize', '-mllvm', '-enable-post-misched=0'], {}),
+        'nomisched': (BASE + ['-fno-slp-vectorize', '-mllvm', '-enable-misched=0'], {}),
+        'minreg': (BASE + ['-fno-slp-vectorize', '-mllvm', '-amdgpu-sched-strategy=iterative-minreg'], {}),
+        'iter-ilp': (BASE + ['-fno-slp-vectorize', '-mllvm', '-amdgpu-sched-strategy=iterative-ilp'], {}),
+        'max-ilp': (BASE + ['-fno-slp-vectorize', '-mllvm', '-amdgpu-sched-strategy=max-ilp'], {}),
+    },
 }
 
 
@@ -55,7 +63,13 @@ def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
         kwargs = {}
         if isinstance(opts, tuple):
             opts, kwargs = opts
-        r = Renderer(scene, seed=0, build_options=opts, **kwargs)
+        if os.environ.get('HINT'):
+            kwargs = dict(kwargs, min_waves_per_simd=int(os.environ['HINT']))
+        try:
+            r = Renderer(scene, seed=0, build_options=opts, **kwargs)
+        except Exception as err:
+            print(name, 'does not build:', str(err)[:150])
+            continue
         if tape is None:
             tape = r.make_tape(0, passes)
         r.upload_tape(tape)
@@ -63,6 +77,7 @@ def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
         rs[name] = r
     ref = None
     times = {k: [] for k in rs}
+    ids0 = t0 = None
     for _ in range(rounds):
         for name, r in rs.items():
             times[name].append(r.render_resident(0, passes))
@@ -73,7 +88,7 @@ def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
         if ref is None:
             ref = img
         ids, t, _ = r.first_hit(tape)
-        if name == 'parity':
+        if ids0 is None:
             ids0, t0 = ids, t
         rmse = np.sqrt(np.mean((img - ref) ** 2)) / np.sqrt(np.mean(ref ** 2))
         ms = np.median(times[name])

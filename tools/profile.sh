@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline $PROFILE_ARGS"
+BENCH="python3 $R/bench.py --no-cpu-baseline $PROFILE_ARGS"
 # bench.py compiles its programs in child processes (program_cache.py); under the profiler no
 # child may start, so an un-profiled run first fills an opt-in program store inside the tree and
 # the profiled runs load the same code objects from it
