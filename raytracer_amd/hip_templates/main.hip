@@ -199,13 +199,18 @@ CLR_FN BounceSample clr_draw_bounce(const uint seed_lo, const uint seed_hi, cons
 // primary ray of one pass (static.cl:109-131): rows of the jitter rotation in rec[0..2],
 // rec[3] = (dof offset, sharp distance), rec[4] = (camera origin, initial path colour scale)
 CLR_FN void clr_start_path(PathState &s, const float4 * __restrict__ rec, const vec3 base_ray) {
-    const vec3 rot_ray = make_vec3(dot(make_vec3(rec[0]), base_ray), dot(make_vec3(rec[1]), base_ray),
-                                   dot(make_vec3(rec[2]), base_ray));
-    const float sharp_distance = rec[3].w;
-    if (sharp_distance > 0.0f) s.ray = fast_normalize(sharp_distance * rot_ray - make_vec3(rec[3]));
-    else s.ray = rot_ray;
-    s.pos = make_vec3(rec[4]);
-    s.ray_color = COLOR_ONE * rec[4].w;
+    // the five records are fetched together and the depth-of-field branch is a select: as a branch
+    // it splits the loads into three dependent round trips per pass
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+    const vec3 rot_ray = make_vec3(dot(make_vec3(r0), base_ray), dot(make_vec3(r1), base_ray),
+                                   dot(make_vec3(r2), base_ray));
+    const float sharp_distance = r3.w;
+    const vec3 focused = fast_normalize(sharp_distance * rot_ray - make_vec3(r3));
+    s.ray.x = sharp_distance > 0.0f ? focused.x : rot_ray.x;
+    s.ray.y = sharp_distance > 0.0f ? focused.y : rot_ray.y;
+    s.ray.z = sharp_distance > 0.0f ? focused.z : rot_ray.z;
+    s.pos = make_vec3(r4);
+    s.ray_color = COLOR_ONE * r4.w;
     s.whichobject = 0;
     s.which_subobject = 0;
     s.inside = {{ renderer.root_object_id }};
