@@ -229,44 +229,57 @@
                 POOL_SYNC();
             }
             const int total = pool_scan[wave_base + n_lanes - 1];
-            for (int base = 0; base < total; base += n_lanes) {
-                const int w = base + rank;
+            // Work item w = (owner lane, triangle j of its leaf).  Two stages, software-pipelined:
+            // while the record of item w is on its way from memory, the owner of item w + n_lanes
+            // is looked up (a binary search over the prefix sums in LDS) and its record requested.
+            struct PoolItem { int owner, j, face; clr_f4u r0, r1; float r2; };   // owner < 0: none
+            auto pool_fetch = [&](const int w) {
+                PoolItem it;
+                it.owner = -1;
                 if (w < total) {
                     int lo = 0, hi = n_lanes - 1;                 // first rank whose prefix sum exceeds w
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
                         if (pool_scan[wave_base + mid] > w) hi = mid; else lo = mid + 1;
                     }
-                    const int owner = pool_owner[wave_base + lo];
-                    const int j = w - (lo ? pool_scan[wave_base + lo - 1] : 0);
-                    const float4 o4 = pool_origin[owner], d4 = pool_ray[owner];
-                    const int record = pool_first[owner] + j;
+                    it.owner = pool_owner[wave_base + lo];
+                    it.j = w - (lo ? pool_scan[wave_base + lo - 1] : 0);
+                    const int record = pool_first[it.owner] + it.j;
                     const float * __restrict__ rec = tris + 9*record;
-                    const clr_f4u r0 = *(const clr_f4u *)rec, r1 = *(const clr_f4u *)(rec + 4);
-                    const float r2 = rec[8];
-                    const int skip_face = __float_as_int(d4.w);
-                    if (skip_face < 0 || tri_ids[record] != skip_face) {
-                        const vec3 o_ray = make_vec3(d4), o_origin = make_vec3(o4);
-                        const vec3 va = make_vec3(r0.x, r0.y, r0.z);
-                        const vec3 e1 = make_vec3(r0.w, r1.x, r1.y);
-                        const vec3 e2 = make_vec3(r1.z, r1.w, r2);
-                        const vec3 pvec = cross(o_ray, e2);
-                        const float det = dot(e1, pvec);
-                        const float inv_det = 1.f / det;
-                        const vec3 tvec = o_origin - va;
-                        const float u = dot(tvec, pvec) * inv_det;
-                        if (!(u < 0.f || u > 1.f)) {
-                            const vec3 qvec = cross(tvec, e1);
-                            const float v = dot(o_ray, qvec) * inv_det;
-                            if (!(v < 0.f || u + v > 1.f)) {
-                                const float t = dot(e2, qvec) * inv_det;
-                                if (t > 0.0f && t < o4.w)
-                                    atomicMin(&pool_best[owner],
-                                              ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)j);
-                            }
+                    it.r0 = *(const clr_f4u *)rec; it.r1 = *(const clr_f4u *)(rec + 4);
+                    it.r2 = rec[8];
+                    // the face number matters only to a ray that starts on a face of this mesh
+                    it.face = __float_as_int(pool_ray[it.owner].w) < 0 ? -2 : tri_ids[record];
+                }
+                return it;
+            };
+            PoolItem cur = pool_fetch(rank);
+            for (int base = 0; base < total; base += n_lanes) {
+                const PoolItem next = pool_fetch(base + n_lanes + rank);
+                float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = o4;
+                if (cur.owner >= 0) { o4 = pool_origin[cur.owner]; d4 = pool_ray[cur.owner]; }
+                if (cur.owner >= 0 && cur.face != __float_as_int(d4.w)) {
+                    const vec3 o_ray = make_vec3(d4), o_origin = make_vec3(o4);
+                    const vec3 va = make_vec3(cur.r0.x, cur.r0.y, cur.r0.z);
+                    const vec3 e1 = make_vec3(cur.r0.w, cur.r1.x, cur.r1.y);
+                    const vec3 e2 = make_vec3(cur.r1.z, cur.r1.w, cur.r2);
+                    const vec3 pvec = cross(o_ray, e2);
+                    const float det = dot(e1, pvec);
+                    const float inv_det = 1.f / det;
+                    const vec3 tvec = o_origin - va;
+                    const float u = dot(tvec, pvec) * inv_det;
+                    if (!(u < 0.f || u > 1.f)) {
+                        const vec3 qvec = cross(tvec, e1);
+                        const float v = dot(o_ray, qvec) * inv_det;
+                        if (!(v < 0.f || u + v > 1.f)) {
+                            const float t = dot(e2, qvec) * inv_det;
+                            if (t > 0.0f && t < o4.w)
+                                atomicMin(&pool_best[cur.owner],
+                                          ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)cur.j);
                         }
                     }
                 }
+                cur = next;
             }
             POOL_SYNC();
 
