@@ -324,7 +324,7 @@ class Renderer:
             acc.set_global('clr_material_colors', self.material_colors)
             acc.set_global('clr_material_scalars', self.material_scalars)
 
-    def tune_occupancy(self, candidates=(None, 3, 4, 5, 6, 8), passes=16, rounds=7, verbose=False):
+    def tune_occupancy(self, candidates=(None, 4, 5, 6, 7, 8), passes=16, rounds=7, verbose=False):
         """Pick the occupancy hint of the render kernel (second __launch_bounds__ argument) by
         timing: the register allocation of these scene-specialised kernels lands on either side
         of a waves-per-SIMD boundary more or less by chance, and one more resident wave or a few

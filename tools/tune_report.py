@@ -8,7 +8,7 @@ from raytracer_amd.hip_compiler import PARITY_OPTIONS
 
 extra = os.environ.get('EXTRA_OPTS', '').split()
 
-candidates = (None, 3, 4, 5, 6, 8)
+candidates = (None, 4, 5, 6, 7, 8)
 for name in sys.argv[1:] or ['scene-dev', 'scene-three-objects']:
     r = Renderer(load_scene(name, (1920, 1080)), seed=0, build_options=PARITY_OPTIONS + extra)
     passes = 4 if 'mesh' in name or 'march' in name else 32
