@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument('--occupancy-hint', default='auto',
                     help="waves per SIMD the render kernel is compiled for: 'auto' (time the candidates "
                          "before the run), 'none' or a number")
+    ap.add_argument('--split-passes', type=int, default=None,
+                    help='1/0: pass-split program (several lanes per pixel) on/off; default: on for small frames')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
@@ -141,7 +143,8 @@ def main():
     r = Renderer(scene, seed=args.seed, device_index=local_rank, ray_range=ray_range,
                  min_waves_per_simd=hint, rng_mode=args.rng,
                  build_options=args.build_options.split() if args.build_options else None,
-                 bake_parameters=None if args.bake is None else bool(args.bake))
+                 bake_parameters=None if args.bake is None else bool(args.bake),
+                 split_passes=None if args.split_passes is None else bool(args.split_passes))
     if args.regenerate is not None:
         r.regenerate = bool(args.regenerate)
     if args.rng == 'philox' and not tiles_requested(args, world):
@@ -206,6 +209,7 @@ def main():
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'speculative_exact_arithmetic': bool(r.speculate),
                    'occupancy_hint': r.min_waves_per_simd,
+                   'pass_groups': r._split_args(args.passes_per_step)['pass_groups'] if r.split_passes else 1,
                    'parallelism': ('%s x%d, one all-reduce' % ('tile-partitioned' if tiles else 'pass-striped', world))
                                   if world > 1 else 'single GPU'},
     }

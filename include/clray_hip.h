@@ -105,6 +105,14 @@ typedef struct clr_render_args {
     int per_pixel_rng;
     unsigned rng_seed_lo, rng_seed_hi;
     int first_pass, first_ray;
+    /* pass-split programs (generated for small frames, where one lane per pixel leaves most of
+     * the GPU idle; no counterpart in the reference): the passes of a pixel are dealt out to
+     * `pass_groups` lanes, which log their addends to pass_log (n_passes x (1 + 2 max_bounces) x
+     * n_pixels float4, device memory), and a second kernel adds the log to img in pass order -
+     * the same additions in the same order as the one-lane walk.  pass_groups >= 1 and a
+     * non-NULL pass_log are required for such a program and must be 0 / NULL for any other. */
+    void *pass_log;
+    int pass_groups;
 } clr_render_args;
 
 int clr_render_passes(clr_program *prog, const clr_render_args *args, void *stream,

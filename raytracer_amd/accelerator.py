@@ -35,7 +35,8 @@ class RenderArgs(ctypes.Structure):
                 ('n_passes', ctypes.c_int), ('regenerate', ctypes.c_int),
                 ('debug_dump', ctypes.c_void_p), ('per_pixel_rng', ctypes.c_int),
                 ('rng_seed_lo', ctypes.c_uint), ('rng_seed_hi', ctypes.c_uint),
-                ('first_pass', ctypes.c_int), ('first_ray', ctypes.c_int)]
+                ('first_pass', ctypes.c_int), ('first_ray', ctypes.c_int),
+                ('pass_log', ctypes.c_void_p), ('pass_groups', ctypes.c_int)]
 
 
 class OctreeInfo(ctypes.Structure):

@@ -40,8 +40,9 @@ struct clr_ctx {
 struct clr_program {
     clr_ctx *ctx;
     hipModule_t module;
-    hipFunction_t render, first_hit;
+    hipFunction_t render, first_hit, reduce_log;
     int rng_mode;      // 1: the program draws per-pixel random numbers, 0: it reads the bounce tape
+    int split_mode;    // 1: clr_render logs addends per pass and clr_reduce_log sums them
 };
 
 namespace {
@@ -214,11 +215,15 @@ int load_program(clr_ctx *ctx, const void *binary, clr_program **out) {
     // a program for clr_launch only (unit kernels) need not hold the two fixed entry kernels
     if (hipModuleGetFunction(&prog->render, prog->module, "clr_render") != hipSuccess) prog->render = nullptr;
     if (hipModuleGetFunction(&prog->first_hit, prog->module, "clr_first_hit") != hipSuccess) prog->first_hit = nullptr;
+    if (hipModuleGetFunction(&prog->reduce_log, prog->module, "clr_reduce_log") != hipSuccess) prog->reduce_log = nullptr;
     prog->rng_mode = 0;
+    prog->split_mode = 0;
     hipDeviceptr_t flag;
     size_t flag_size = 0;
     if (hipModuleGetGlobal(&flag, &flag_size, prog->module, "clr_rng_mode") == hipSuccess && flag_size == sizeof(int))
         (void)hipMemcpyDtoH(&prog->rng_mode, flag, sizeof(int));
+    if (hipModuleGetGlobal(&flag, &flag_size, prog->module, "clr_split_mode") == hipSuccess && flag_size == sizeof(int))
+        (void)hipMemcpyDtoH(&prog->split_mode, flag, sizeof(int));
     (void)hipGetLastError();
     *out = prog;
     return 0;
@@ -302,6 +307,13 @@ int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream,
         return fail("clr_render_passes: bounce_tape is required for a tape program");
     if (a->debug_dump && a->n_passes != 1)
         return fail("clr_render_passes: debug_dump needs n_passes == 1");
+    if (prog->split_mode) {
+        if (!prog->reduce_log) return fail("clr_render_passes: the pass-split program has no kernel clr_reduce_log");
+        if (a->pass_groups < 1 || !a->pass_log)
+            return fail("clr_render_passes: a pass-split program needs pass_groups >= 1 and a pass_log buffer");
+    }
+    else if (a->pass_groups != 0 || a->pass_log)
+        return fail("clr_render_passes: pass_groups / pass_log given, but the program was not generated in pass-split mode");
     if (a->n_passes == 0) { if (elapsed_ms) *elapsed_ms = 0.0f; return 0; }
     void *img = a->img;
     const void *cam = a->cam, *pt = a->pass_tape, *bt = a->bounce_tape, *mr = a->material_rows,
@@ -310,11 +322,32 @@ int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream,
     void *dbg = a->debug_dump;
     unsigned seed_lo = a->rng_seed_lo, seed_hi = a->rng_seed_hi;
     int first_pass = a->first_pass, first_ray = a->first_ray;
+    void *pass_log = a->pass_log;
+    int pass_groups = a->pass_groups;
     void *args[] = {&img, &cam, &pt, &bt, &mr, &vd, &id, &n_pixels, &n_passes, &regen, &dbg,
-                    &seed_lo, &seed_hi, &first_pass, &first_ray};
-    const unsigned grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
+                    &seed_lo, &seed_hi, &first_pass, &first_ray, &pass_log, &pass_groups};
     const unsigned block[3] = {kBlock, 1, 1};
-    return launch(prog->ctx, prog->render, grid, block, args, stream, elapsed_ms);
+    if (!prog->split_mode) {
+        const unsigned grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
+        return launch(prog->ctx, prog->render, grid, block, args, stream, elapsed_ms);
+    }
+    // pass-split program: n_pixels x pass_groups lanes write the log, then one lane per pixel sums it
+    const unsigned long long lanes = (unsigned long long)n_pixels * (unsigned)pass_groups;
+    if (lanes > 0x7fffffffull) return fail("clr_render_passes: n_pixels x pass_groups is too large");
+    const unsigned grid[3] = {(unsigned)((lanes + kBlock - 1) / kBlock), 1, 1};
+    const unsigned reduce_grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
+    const void *log_in = pass_log;
+    void *reduce_args[] = {&img, &log_in, &n_pixels, &n_passes};
+    hipStream_t s = (hipStream_t)stream;
+    if (elapsed_ms) CLR_TRY(hipEventRecord(prog->ctx->ev_start, s));
+    CLR_TRY(hipModuleLaunchKernel(prog->render, grid[0], 1, 1, kBlock, 1, 1, 0, s, args, nullptr));
+    CLR_TRY(hipModuleLaunchKernel(prog->reduce_log, reduce_grid[0], 1, 1, kBlock, 1, 1, 0, s, reduce_args, nullptr));
+    if (elapsed_ms) {
+        CLR_TRY(hipEventRecord(prog->ctx->ev_stop, s));
+        CLR_TRY(hipEventSynchronize(prog->ctx->ev_stop));
+        CLR_TRY(hipEventElapsedTime(elapsed_ms, prog->ctx->ev_start, prog->ctx->ev_stop));
+    }
+    return 0;
 }
 
 int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape, const void *vector_data,

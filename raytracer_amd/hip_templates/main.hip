@@ -31,6 +31,10 @@ static __shared__ float clr_lds_material_scalars[{{ 5*(n_objects+1) }}];
 // 1: every pixel draws its own random numbers (clr_rng.inl), 0: they come from the bounce tape;
 // read by the host library to check the launch arguments against the program
 __constant__ int clr_rng_mode = {{ 1 if renderer.rng_mode == 'philox' else 0 }};
+// 1: pass-split program (clr_render writes a log of addends per pass, clr_reduce_log sums it);
+// read by the host library like clr_rng_mode
+__constant__ int clr_split_mode = {{ 1 if renderer.split_passes else 0 }};
+#define CLR_LOG_SLOTS {{ 1 + 2*renderer.scene.max_bounces }}   // per (pass, pixel): count, then the addends
 ### if renderer.rng_mode == 'philox'
 // next-event lights (spheres): (centre, R), (area, minimum sampling distance, object id bits, 0)
 __constant__ float4 clr_lights[{{ [2*renderer.n_lights, 2]|max }}];
@@ -225,7 +229,7 @@ CLR_FN void clr_start_path(PathState &s, const float4 * __restrict__ rec, const 
 // the two object sweeps: speculative short sequences or the generic ones (clr_exact.inl).
 template<class CLR_G>
 CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last, const vec3 cmask,
-    vec3 &img, const float * __restrict__ material_row,
+    clr_acc &img, const float * __restrict__ material_row,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
     float4 * __restrict__ dbg, CLR_G &clr_g)
 {
@@ -273,7 +277,7 @@ CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last,
 ### if renderer.speculate
 // the replay of a segment with the generic arithmetic: rare, kept out of the render loop
 static __device__ __attribute__((noinline)) bool clr_segment_generic(PathState *s, const BounceSample *B,
-    const bool is_last, const vec3 cmask, vec3 *img, const float * __restrict__ material_row,
+    const bool is_last, const vec3 cmask, clr_acc *img, const float * __restrict__ material_row,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, float4 * __restrict__ dbg)
 {
     return clr_segment(*s, *B, is_last, cmask, *img, material_row, vector_data, integer_data, dbg, clr_g);
@@ -296,13 +300,28 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
            const float * __restrict__ material_rows,
            const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
            const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg,
-           const uint rng_seed_lo, const uint rng_seed_hi, const int first_pass, const int first_ray)
+           const uint rng_seed_lo, const uint rng_seed_hi, const int first_pass, const int first_ray,
+           float4 * __restrict__ pass_log, const int pass_groups)
 {
+### if renderer.split_passes
+    // pass-split mode: lane (k, group) walks the passes [group * per_group, ...) of pixel k and
+    // logs what it would have added to the pixel: pass_log[(pass * CLR_LOG_SLOTS + slot) * n_pixels + k]
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = lane % n_pixels, group = lane / n_pixels;
+    const bool in_image = group < pass_groups;
+    const int per_group = (n_passes + pass_groups - 1) / pass_groups;
+    const int pass_begin = in_image ? min(group * per_group, n_passes) : n_passes;
+    const int pass_end = in_image ? min(pass_begin + per_group, n_passes) : n_passes;
+    const int kk = k;
+    const vec3 base_ray = make_vec3(cam[kk]);
+### else
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_image = k < n_pixels;
+    const int pass_begin = 0, pass_end = n_passes;
     const int kk = in_image ? k : 0;
     const vec3 base_ray = make_vec3(cam[kk]);
     const float4 img0 = img[kk];
+### endif
 ### if shader.rgb and renderer.materials_in_lds
     for (int i = threadIdx.x; i < {{ 5*(n_objects+1) }}; i += blockDim.x) {
         clr_lds_material_colors[i] = clr_material_colors[i];
@@ -310,28 +329,43 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
     }
     __syncthreads();
 ### endif
-    vec3 acc = make_vec3(img0.x, img0.y, img0.z);
+    clr_acc acc;
+### if renderer.split_passes
+    acc.stride = (size_t)n_pixels;
+    acc.n = 0;
+    acc.log = pass_log + k;
+### else
+    acc.v = make_vec3(img0.x, img0.y, img0.z);
+### endif
 
     PathState s;
-    int pass = in_image ? 0 : n_passes;
+    int pass = in_image ? pass_begin : pass_end;
     int segment = 0;
     bool active = false;
     vec3 cmask = make_vec3(1.0f, 1.0f, 1.0f);
 ### if renderer.speculate
-    vec3 acc_at_pass_start = acc;
+    ### if not renderer.split_passes
+    vec3 acc_at_pass_start = acc.v;
+    ### endif
     bool generic_path = false;
 ### endif
 
     for (;;) {
         const bool wave_busy = __any(active);
-        if (!active && pass < n_passes && (regen || !wave_busy)) {
+        if (!active && pass < pass_end && (regen || !wave_busy)) {
             const float4 *rec = pass_tape + (size_t)pass * CLR_PASS_STRIDE;
             clr_start_path(s, rec, base_ray);
             cmask = make_vec3(rec[5]);
             segment = 0;
             active = true;
+### if renderer.split_passes
+            acc.log = pass_log + (size_t)pass * CLR_LOG_SLOTS * n_pixels + k;
+            acc.n = 0;
+### endif
 ### if renderer.speculate
-            acc_at_pass_start = acc;
+    ### if not renderer.split_passes
+            acc_at_pass_start = acc.v;
+    ### endif
             generic_path = false;
 ### endif
         }
@@ -359,7 +393,11 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
                 clr_guard_reset(spec);
                 alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, spec);
                 if (!clr_guard_ok(spec)) {
-                    acc = acc_at_pass_start;
+    ### if renderer.split_passes
+                    acc.n = 0;
+    ### else
+                    acc.v = acc_at_pass_start;
+    ### endif
                     clr_start_path(s, pass_tape + (size_t)pass * CLR_PASS_STRIDE, base_ray);
                     segment = 0;
                     generic_path = true;
@@ -369,7 +407,7 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
             else {
                 // only copies of the state escape to the callee
                 PathState s1 = s;
-                vec3 acc1 = acc;
+                clr_acc acc1 = acc;
                 BounceSample B1 = B;
                 alive = clr_segment_generic(&s1, &B1, is_last, cmask, &acc1, material_row, vector_data, integer_data, d);
                 s = s1;
@@ -379,11 +417,39 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
             const bool alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, clr_g);
 ### endif
             segment++;
-            if (!alive) { active = false; pass++; }
+            if (!alive) {
+### if renderer.split_passes
+                acc.log[0] = make_float4(__int_as_float(acc.n), 0.0f, 0.0f, 0.0f);
+### endif
+                active = false;
+                pass++;
+            }
         }
     }
-    if (in_image) img[k] = make_float4(acc.x, acc.y, acc.z, img0.w);
+### if not renderer.split_passes
+    if (in_image) img[k] = make_float4(acc.v.x, acc.v.y, acc.v.z, img0.w);
+### endif
 }
+
+### if renderer.split_passes
+// Second step of pass-split mode: the logged addends of every pass, added to the pixel in pass
+// order and, inside a pass, in the order in which the path produced them.
+extern "C" __global__ void __launch_bounds__(256)
+clr_reduce_log(float4 * __restrict__ img, const float4 * __restrict__ pass_log,
+               const int n_pixels, const int n_passes)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pixels) return;
+    const float4 img0 = img[k];
+    vec3 acc = make_vec3(img0.x, img0.y, img0.z);
+    for (int pass = 0; pass < n_passes; ++pass) {
+        const float4 *log = pass_log + (size_t)pass * CLR_LOG_SLOTS * n_pixels + k;
+        const int n = __float_as_int(log[0].x);
+        for (int i = 0; i < n; ++i) acc += make_vec3(log[(size_t)(1 + i) * n_pixels]);
+    }
+    img[k] = make_float4(acc.x, acc.y, acc.z, img0.w);
+}
+### endif
 
 // First-hit AOV for the primary rays of pass record 0: object id, sub-object, distance, normal.
 extern "C" __global__ void __launch_bounds__(256)

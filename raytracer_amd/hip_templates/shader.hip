@@ -32,6 +32,25 @@ CLR_FN vec3 color_to_rgb(float c, vec3 cmask) { return c * cmask; }
 
 #define CLR_PI_F 3.14159274101257324f
 
+// Where a path's radiance goes.  Normally a running sum in registers.  In pass-split mode
+// (small frames: several lanes per pixel, each with a range of passes; main.hip) the addends are
+// written to a log in the order of the additions, and clr_reduce_log adds them to the pixel in
+// pass order afterwards - the same additions in the same order, hence the same bits.
+struct clr_acc {
+### if renderer.split_passes
+    float4 *log;          // slot 0 of this lane's current pass; slots are n_pixels apart
+    size_t stride;
+    int n;
+    CLR_FN_MEMBER void operator+=(const vec3 a) {
+        log[(size_t)(1 + n) * stride] = make_float4(a.x, a.y, a.z, 0.0f);
+        n++;
+    }
+### else
+    vec3 v;
+    CLR_FN_MEMBER void operator+=(const vec3 a) { v += a; }
+### endif
+};
+
 struct PathState {
     vec3 pos, ray;
     color_t ray_color;
@@ -65,7 +84,7 @@ struct BounceSample {                    // one record of the random tape (SURVE
 // normal n, segment length last_dist).  Adds radiance to `img`.  Returns false if the path
 // is finished (last segment, or culled).
 CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const float shadow_mask,
-                      const BounceSample &B, const bool is_last, const vec3 cmask, vec3 &img
+                      const BounceSample &B, const bool is_last, const vec3 cmask, clr_acc &img
 ### if not shader.rgb
                       , const float * __restrict__ material_scalars
 ### endif

@@ -23,11 +23,17 @@ BOUNCE_RECORD = 5    # float4 per path segment in the tape
 DEBUG_RECORD = 6     # float4 per (segment, pixel) in the debug dump
 
 
+# lanes that fill an MI355X: 256 CUs x 4 SIMDs x 6 waves x 64
+FULL_GPU_LANES = 256 * 4 * 6 * 64
+# lanes a pass-split launch aims for (several rounds of waves even out the tail)
+SPLIT_LANES = 4 * FULL_GPU_LANES
+
+
 class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
-                 min_waves_per_simd=None, speculate=None, rng_mode='tape'):
+                 min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None):
         self.scene = scene
         # tile partitioning: (first ray, count) in ray order; a contiguous range of ray
         # indices is a set of 4-pixel-wide column blocks of the frame (get_image_order)
@@ -58,6 +64,15 @@ class Renderer:
         if speculate is None:
             speculate = all(getattr(obj.tracer, 'speculation_friendly', False) for obj in scene.objects)
         self.speculate = speculate
+        # Pass-split mode for small frames.  One lane per pixel gives a 320 x 240 frame 1200 waves
+        # for 1024 SIMDs that each want 4-8; the program then deals the passes of a pixel out to
+        # several lanes, which log their addends, and a second kernel sums the logs in pass order
+        # (hip_templates/main.hip; same additions in the same order, same bits).  Measured:
+        # scene-test 320 x 240 32 -> 275 Msamples/s, scene-dev 320 x 240 4.1 -> 10.8 Gsamples/s;
+        # from 640 x 480 on the log costs a light kernel more than the extra lanes bring, so the
+        # default is: on when the frame has at most half the lanes that fill the GPU.
+        self.split_passes = (2 * self.n_pixels <= FULL_GPU_LANES) if split_passes is None else bool(split_passes)
+        self._pass_log = None
         # optional occupancy hint for the render kernel (second __launch_bounds__ argument)
         self.min_waves_per_simd = min_waves_per_simd
         # small scenes: bake the per-object parameters into the program text as literals
@@ -405,6 +420,13 @@ class Renderer:
     def render_resident(self, first, count, stream=None, timed=True):
         """Render passes [first, first + count) of the resident tape (no host transfer)."""
         assert 0 <= first and first + count <= self._resident_passes
+        if self.split_passes:
+            # keep the addend log below 2 GB: longer ranges go as several launches
+            most = max(1, (1 << 31) // ((1 + 2 * self.scene.max_bounces) * self.n_pixels * 16))
+            if count > most:
+                ms = [self.render_resident(f, min(most, first + count - f), stream, timed)
+                      for f in range(first, first + count, most)]
+                return sum(ms) if timed else None
         rows = self.dev_rows[first:first + count].ptr if self.dev_rows is not None else None
         args = RenderArgs(
             img=self.img.ptr, cam=self.cam.ptr,
@@ -413,8 +435,20 @@ class Renderer:
             material_rows=rows,
             vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
             n_pixels=self.n_pixels, n_passes=count, regenerate=int(self.regenerate),
-            debug_dump=None, **self._rng_args(self._resident_first_pass + first))
+            debug_dump=None, **self._split_args(count), **self._rng_args(self._resident_first_pass + first))
         return self.acc.render_passes(args, stream=stream, timed=timed)
+
+    def _split_args(self, n_passes, debug=False):
+        """The pass-split fields of clr_render_args (empty for a one-lane-per-pixel program)."""
+        if not self.split_passes:
+            return {}
+        groups = 1 if debug else max(1, min(n_passes, -(-SPLIT_LANES // self.n_pixels)))
+        groups = -(-n_passes // -(-n_passes // groups))        # same passes per group, fewer idle groups
+        slots = 1 + 2 * self.scene.max_bounces
+        if self._pass_log is None or self._pass_log.shape[0] < n_passes:
+            self._pass_log = None          # release before growing
+            self._pass_log = self.acc.new_array((n_passes, slots, self.n_pixels, 4), np.float32)
+        return dict(pass_log=self._pass_log.ptr, pass_groups=groups)
 
     def _rng_args(self, first_pass):
         """The per-pixel random number fields of clr_render_args."""
@@ -437,7 +471,7 @@ class Renderer:
             material_rows=self.dev_rows.ptr if self.dev_rows is not None else None,
             vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
             n_pixels=self.n_pixels, n_passes=n, regenerate=int(self.regenerate),
-            debug_dump=dump.ptr if dump is not None else None, **self._rng_args(first_pass))
+            debug_dump=dump.ptr if dump is not None else None, **self._split_args(n, debug), **self._rng_args(first_pass))
         ms = self.acc.render_passes(args, stream=stream, timed=timed)
         return ms, (dump.get() if dump is not None else None)
 

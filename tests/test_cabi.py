@@ -31,8 +31,10 @@ def test_python_prototypes_cover_the_header():
 
 
 def test_struct_layout_matches_header():
-    # 7 pointers, 3 ints, padding, pointer, then 5 ints of the per-pixel random number mode + padding
-    assert ctypes.sizeof(accelerator.RenderArgs) == 7 * 8 + 3 * 4 + 4 + 8 + 5 * 4 + 4
+    # 7 pointers, 3 ints, padding, pointer, 5 ints of the per-pixel random number mode + padding,
+    # then the pass-split pair: pointer, int + padding
+    assert ctypes.sizeof(accelerator.RenderArgs) == 7 * 8 + 3 * 4 + 4 + 8 + 5 * 4 + 4 + 8 + 4 + 4
+    assert accelerator.RenderArgs.pass_log.offset == 104 and accelerator.RenderArgs.pass_groups.offset == 112
     assert accelerator.RenderArgs.debug_dump.offset == 72
     assert accelerator.RenderArgs.per_pixel_rng.offset == 80 and accelerator.RenderArgs.first_ray.offset == 96
     assert ctypes.sizeof(accelerator.DeviceInfo) == 128 + 64 + 4 * 4 + 8

@@ -108,7 +108,7 @@ def test_random_scene_bit_exact(seed):
     assert np.isfinite(img).all() and img[:, :3].max() > 0
     assert np.array_equal(bits(img), bits(oimg))
 
-    generic = Renderer(random_scene(seed), seed=seed, speculate=False, bake_parameters=False)
+    generic = Renderer(random_scene(seed), seed=seed, speculate=False, bake_parameters=False, split_passes=False)
     generic.render_tape(first)
     generic.render_tape(rest)
     assert np.array_equal(bits(generic.img.get()), bits(oimg))

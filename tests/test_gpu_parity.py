@@ -478,3 +478,49 @@ def test_random_number_mode_of_program_and_launch_must_agree():
     with pytest.raises(Exception) as err:
         r.render_tape(tape)
     assert 'random number mode' in str(err.value)
+
+
+@pytest.mark.parametrize('name,rng_mode', [('scene-dev', 'tape'), ('scene-three-objects', 'tape'),
+                                           ('scene-test', 'tape'), ('scene-dev', 'philox')])
+def test_pass_split_mode_adds_in_the_same_order(name, rng_mode):
+    """Small frames: the passes of a pixel are dealt out to several lanes that log their addends,
+    and a second kernel sums the logs in pass order.  Same bits as the one-lane walk and as the
+    oracle, for pass counts that do and do not divide by the number of groups, with and without
+    path regeneration, on top of a non-zero image."""
+    from oracle import oracle
+    size = (40, 24)
+    one = Renderer(load_scene(name, size), seed=4, rng_mode=rng_mode, split_passes=False)
+    split = Renderer(load_scene(name, size), seed=4, rng_mode=rng_mode)
+    assert split.split_passes and not one.split_passes
+    osc = oracle.OracleScene(one)
+    oimg = None
+    first = 0
+    for n, regenerate in ((7, False), (1, True), (12, True)):
+        tape = one.make_tape(first, n)
+        for r in (one, split):
+            r.regenerate = regenerate
+            r.render_tape(tape, first_pass=first)
+        oimg, _, _ = osc.render(tape, img=oimg, first_pass=first)
+        first += n
+        assert np.array_equal(bits(one.img.get()), bits(oimg))
+        assert np.array_equal(bits(split.img.get()), bits(oimg))
+    assert split._split_args(12)['pass_groups'] == 12
+    # the debug dump of a split program is that of the one-lane walk
+    tape = one.make_tape(first, 1)
+    assert np.array_equal(bits(one.render_tape(tape, debug=True, first_pass=first)[1]),
+                          bits(split.render_tape(tape, debug=True, first_pass=first)[1]))
+
+
+def test_pass_split_arguments_must_match_the_program():
+    r = Renderer(load_scene('scene-dev', (1920, 1080)), seed=0)
+    assert not r.split_passes
+    tape = r.make_tape(0, 1)
+    r._split_args = lambda n, debug=False: dict(pass_log=r.img.ptr, pass_groups=2)
+    with pytest.raises(Exception) as err:
+        r.render_tape(tape)
+    assert 'pass-split' in str(err.value)
+    small = Renderer(load_scene('scene-dev', (32, 16)), seed=0)
+    small._split_args = lambda n, debug=False: {}
+    with pytest.raises(Exception) as err:
+        small.render_tape(small.make_tape(0, 1))
+    assert 'pass_log' in str(err.value)
