@@ -443,11 +443,12 @@ class Renderer:
         if not self.split_passes:
             return {}
         groups = 1 if debug else max(1, min(n_passes, -(-SPLIT_LANES // self.n_pixels)))
-        groups = -(-n_passes // -(-n_passes // groups))        # same passes per group, fewer idle groups
+        if n_passes > 0:
+            groups = -(-n_passes // -(-n_passes // groups))    # same passes per group, fewer idle groups
         slots = 1 + 2 * self.scene.max_bounces
         if self._pass_log is None or self._pass_log.shape[0] < n_passes:
             self._pass_log = None          # release before growing
-            self._pass_log = self.acc.new_array((n_passes, slots, self.n_pixels, 4), np.float32)
+            self._pass_log = self.acc.new_array((max(n_passes, 1), slots, self.n_pixels, 4), np.float32)
         return dict(pass_log=self._pass_log.ptr, pass_groups=groups)
 
     def _rng_args(self, first_pass):
