@@ -293,6 +293,9 @@ static __device__ __attribute__((noinline)) bool clr_segment_generic(PathState *
 //              always executes a live segment (path regeneration).  Per-pixel results are
 //              identical in both modes: a lane still visits its passes and segments in order.
 // dbg (optional, n_passes == 1): CLR_DBG_STRIDE float4 per (segment, pixel).
+// Pass-split programs (clr_split_mode, small frames): n_pixels x pass_groups lanes; a lane walks a
+// range of the passes of its pixel and logs its addends instead of summing them (clr_acc), img is
+// left to clr_reduce_log.
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_per_simd if renderer.min_waves_per_simd else '' }})
 clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
