@@ -107,8 +107,8 @@ typedef struct clr_render_args {
     int first_pass, first_ray;
     /* pass-split programs (generated for small frames, where one lane per pixel leaves most of
      * the GPU idle; no counterpart in the reference): the passes of a pixel are dealt out to
-     * `pass_groups` lanes, which log their addends to pass_log (n_passes x (1 + 2 max_bounces) x
-     * n_pixels float4, device memory), and a second kernel adds the log to img in pass order -
+     * `pass_groups` lanes, which log their addends to pass_log (n_passes x (1 + 6 max_bounces) x
+     * n_pixels floats, device memory), and a second kernel adds the log to img in pass order -
      * the same additions in the same order as the one-lane walk.  pass_groups >= 1 and a
      * non-NULL pass_log are required for such a program and must be 0 / NULL for any other. */
     void *pass_log;

@@ -34,7 +34,7 @@ __constant__ int clr_rng_mode = {{ 1 if renderer.rng_mode == 'philox' else 0 }};
 // 1: pass-split program (clr_render writes a log of addends per pass, clr_reduce_log sums it);
 // read by the host library like clr_rng_mode
 __constant__ int clr_split_mode = {{ 1 if renderer.split_passes else 0 }};
-#define CLR_LOG_SLOTS {{ 1 + 2*renderer.scene.max_bounces }}   // per (pass, pixel): count, then the addends
+#define CLR_LOG_FLOATS {{ 1 + 6*renderer.scene.max_bounces }}   // per (pass, pixel): header word, then <= 2 addends of 3 floats per segment
 ### if renderer.rng_mode == 'philox'
 // next-event lights (spheres): (centre, R), (area, minimum sampling distance, object id bits, 0)
 __constant__ float4 clr_lights[{{ [2*renderer.n_lights, 2]|max }}];
@@ -304,11 +304,11 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
            const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
            const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg,
            const uint rng_seed_lo, const uint rng_seed_hi, const int first_pass, const int first_ray,
-           float4 * __restrict__ pass_log, const int pass_groups)
+           float * __restrict__ pass_log, const int pass_groups)
 {
 ### if renderer.split_passes
     // pass-split mode: lane (k, group) walks the passes [group * per_group, ...) of pixel k and
-    // logs what it would have added to the pixel: pass_log[(pass * CLR_LOG_SLOTS + slot) * n_pixels + k]
+    // logs what it would have added to the pixel (layout: clr_acc, shader.hip)
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = lane % n_pixels, group = lane / n_pixels;
     const bool in_image = group < pass_groups;
@@ -335,8 +335,7 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
     clr_acc acc;
 ### if renderer.split_passes
     acc.stride = (size_t)n_pixels;
-    acc.n = 0;
-    acc.log = pass_log + k;
+    acc.begin_pass(pass_log, 0, k);
 ### else
     acc.v = make_vec3(img0.x, img0.y, img0.z);
 ### endif
@@ -362,8 +361,7 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
             segment = 0;
             active = true;
 ### if renderer.split_passes
-            acc.log = pass_log + (size_t)pass * CLR_LOG_SLOTS * n_pixels + k;
-            acc.n = 0;
+            acc.begin_pass(pass_log, pass, k);
 ### endif
 ### if renderer.speculate
     ### if not renderer.split_passes
@@ -397,7 +395,7 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
                 alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, spec);
                 if (!clr_guard_ok(spec)) {
     ### if renderer.split_passes
-                    acc.n = 0;
+                    acc.restart_pass();
     ### else
                     acc.v = acc_at_pass_start;
     ### endif
@@ -422,7 +420,7 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
             segment++;
             if (!alive) {
 ### if renderer.split_passes
-                acc.log[0] = make_float4(__int_as_float(acc.n), 0.0f, 0.0f, 0.0f);
+                acc.end_pass();
 ### endif
                 active = false;
                 pass++;
@@ -438,7 +436,7 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
 // Second step of pass-split mode: the logged addends of every pass, added to the pixel in pass
 // order and, inside a pass, in the order in which the path produced them.
 extern "C" __global__ void __launch_bounds__(256)
-clr_reduce_log(float4 * __restrict__ img, const float4 * __restrict__ pass_log,
+clr_reduce_log(float4 * __restrict__ img, const float * __restrict__ pass_log,
                const int n_pixels, const int n_passes)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -446,9 +444,17 @@ clr_reduce_log(float4 * __restrict__ img, const float4 * __restrict__ pass_log,
     const float4 img0 = img[k];
     vec3 acc = make_vec3(img0.x, img0.y, img0.z);
     for (int pass = 0; pass < n_passes; ++pass) {
-        const float4 *log = pass_log + (size_t)pass * CLR_LOG_SLOTS * n_pixels + k;
-        const int n = __float_as_int(log[0].x);
-        for (int i = 0; i < n; ++i) acc += make_vec3(log[(size_t)(1 + i) * n_pixels]);
+        const float *header = pass_log + (size_t)pass * CLR_LOG_FLOATS * n_pixels + k;
+        const float *entries = header - k + n_pixels + 3 * (size_t)k;
+        const int word = __float_as_int(*header);
+        const int n = word & 0xff, first_plus_zero = word >> 8;
+        for (int i = 0; i <= n; ++i) {
+            if (first_plus_zero == i + 1) acc += make_vec3(0.0f, 0.0f, 0.0f);
+            if (i < n) {
+                const float *e = entries + (size_t)i * 3 * n_pixels;
+                acc += make_vec3(e[0], e[1], e[2]);
+            }
+        }
     }
     img[k] = make_float4(acc.x, acc.y, acc.z, img0.w);
 }

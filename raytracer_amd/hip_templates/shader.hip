@@ -36,15 +36,34 @@ CLR_FN vec3 color_to_rgb(float c, vec3 cmask) { return c * cmask; }
 // (small frames: several lanes per pixel, each with a range of passes; main.hip) the addends are
 // written to a log in the order of the additions, and clr_reduce_log adds them to the pixel in
 // pass order afterwards - the same additions in the same order, hence the same bits.
+// Most addends are (+0, +0, +0) (the emission of a surface that does not emit) and are not logged:
+// adding +0 changes a sum only while it is -0, and after the first such addition no component can
+// become -0 again (x + y = -0 needs x = y = -0), so the log keeps just the position of the first
+// one.  Per (pass, pixel): one header word, n | (1 + entries before the first +0 addend, 0 = none)
+// << 8, in a plane of n_pixels words, then the entries, 3 floats each, in planes of 3 n_pixels.
 struct clr_acc {
 ### if renderer.split_passes
-    float4 *log;          // slot 0 of this lane's current pass; slots are n_pixels apart
-    size_t stride;
-    int n;
+    float *header;        // this lane's header word of the current pass
+    float *entries;       // its entry 0; entry i is 3 i stride floats further on
+    size_t stride;        // n_pixels
+    int n, first_plus_zero;
     CLR_FN_MEMBER void operator+=(const vec3 a) {
-        log[(size_t)(1 + n) * stride] = make_float4(a.x, a.y, a.z, 0.0f);
+        if ((__float_as_int(a.x) | __float_as_int(a.y) | __float_as_int(a.z)) == 0) {
+            if (first_plus_zero == 0) first_plus_zero = n + 1;
+            return;
+        }
+        float *e = entries + (size_t)n * 3 * stride;
+        e[0] = a.x; e[1] = a.y; e[2] = a.z;
         n++;
     }
+    CLR_FN_MEMBER void begin_pass(float *pass_log, const int pass, const int k) {
+        header = pass_log + (size_t)pass * CLR_LOG_FLOATS * stride + k;
+        entries = header - k + stride + 3 * (size_t)k;
+        n = 0;
+        first_plus_zero = 0;
+    }
+    CLR_FN_MEMBER void restart_pass() { n = 0; first_plus_zero = 0; }
+    CLR_FN_MEMBER void end_pass() { *header = __int_as_float(n | (first_plus_zero << 8)); }
 ### else
     vec3 v;
     CLR_FN_MEMBER void operator+=(const vec3 a) { v += a; }

@@ -68,10 +68,10 @@ class Renderer:
         # for 1024 SIMDs that each want 4-8; the program then deals the passes of a pixel out to
         # several lanes, which log their addends, and a second kernel sums the logs in pass order
         # (hip_templates/main.hip; same additions in the same order, same bits).  Measured:
-        # scene-test 320 x 240 32 -> 275 Msamples/s, scene-dev 320 x 240 4.1 -> 10.8 Gsamples/s;
-        # from 640 x 480 on the log costs a light kernel more than the extra lanes bring, so the
-        # default is: on when the frame has at most half the lanes that fill the GPU.
-        self.split_passes = (2 * self.n_pixels <= FULL_GPU_LANES) if split_passes is None else bool(split_passes)
+        # scene-test 320 x 240 32 -> 275 Msamples/s, scene-dev 320 x 240 4.1 -> 11.8 Gsamples/s,
+        # 800 x 600 (the reference's default size) 16.8 -> 19.2; at 1080p the log costs a light
+        # kernel 11 %, so the default is: on up to 1.5 x the lanes that fill the GPU.
+        self.split_passes = (2 * self.n_pixels <= 3 * FULL_GPU_LANES) if split_passes is None else bool(split_passes)
         self._pass_log = None
         # optional occupancy hint for the render kernel (second __launch_bounds__ argument)
         self.min_waves_per_simd = min_waves_per_simd
@@ -422,7 +422,7 @@ class Renderer:
         assert 0 <= first and first + count <= self._resident_passes
         if self.split_passes:
             # keep the addend log below 2 GB: longer ranges go as several launches
-            most = max(1, (1 << 31) // ((1 + 2 * self.scene.max_bounces) * self.n_pixels * 16))
+            most = max(1, (1 << 31) // ((1 + 6 * self.scene.max_bounces) * self.n_pixels * 4))
             if count > most:
                 ms = [self.render_resident(f, min(most, first + count - f), stream, timed)
                       for f in range(first, first + count, most)]
@@ -445,10 +445,10 @@ class Renderer:
         groups = 1 if debug else max(1, min(n_passes, -(-SPLIT_LANES // self.n_pixels)))
         if n_passes > 0:
             groups = -(-n_passes // -(-n_passes // groups))    # same passes per group, fewer idle groups
-        slots = 1 + 2 * self.scene.max_bounces
+        floats = 1 + 6 * self.scene.max_bounces
         if self._pass_log is None or self._pass_log.shape[0] < n_passes:
             self._pass_log = None          # release before growing
-            self._pass_log = self.acc.new_array((max(n_passes, 1), slots, self.n_pixels, 4), np.float32)
+            self._pass_log = self.acc.new_array((max(n_passes, 1), floats, self.n_pixels), np.float32)
         return dict(pass_log=self._pass_log.ptr, pass_groups=groups)
 
     def _rng_args(self, first_pass):
