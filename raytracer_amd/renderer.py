@@ -29,6 +29,16 @@ FULL_GPU_LANES = 256 * 4 * 6 * 64
 SPLIT_LANES = 4 * FULL_GPU_LANES
 
 
+def pass_groups_for(n_pixels, n_passes):
+    """Lanes per pixel of a pass-split launch: enough for SPLIT_LANES lanes, at most one group per
+    pass, and no more groups than ceil(n_passes / passes per group) can use."""
+    if n_passes <= 0:
+        return 1
+    groups = max(1, min(n_passes, -(-SPLIT_LANES // n_pixels)))
+    per_group = -(-n_passes // groups)
+    return -(-n_passes // per_group)
+
+
 class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
@@ -442,9 +452,7 @@ class Renderer:
         """The pass-split fields of clr_render_args (empty for a one-lane-per-pixel program)."""
         if not self.split_passes:
             return {}
-        groups = 1 if debug else max(1, min(n_passes, -(-SPLIT_LANES // self.n_pixels)))
-        if n_passes > 0:
-            groups = -(-n_passes // -(-n_passes // groups))    # same passes per group, fewer idle groups
+        groups = 1 if debug else pass_groups_for(self.n_pixels, n_passes)
         floats = 1 + 6 * self.scene.max_bounces
         if self._pass_log is None or self._pass_log.shape[0] < n_passes:
             self._pass_log = None          # release before growing

@@ -293,3 +293,16 @@ def test_parallelepiped_light_interface():
         counts[int(np.argmax(on_face))] = counts.get(int(np.argmax(on_face)), 0) + 1
     share = np.array([counts[i] for i in range(3)]) / 3000.0       # faces normal to x, y, z
     assert np.allclose(share, np.array([0.5, 1.0, 2.0]) / 3.5, atol=0.03)
+
+
+def test_pass_split_policy():
+    """Which frames get the pass-split program and how many lanes share a pixel (renderer.py)."""
+    from raytracer_amd.renderer import pass_groups_for
+    assert pass_groups_for(320 * 240, 16) == 16
+    assert pass_groups_for(640 * 480, 32) == 6
+    assert pass_groups_for(800 * 600, 32) == 4
+    assert pass_groups_for(800 * 600, 1) == 1 and pass_groups_for(800 * 600, 0) == 1
+    assert pass_groups_for(64 * 48, 7) == 7                       # never more groups than passes
+    assert pass_groups_for(320 * 240, 30) == 15                   # 21 lanes wanted, 2 passes per group: 15 groups
+    for size, split in (((320, 240), True), ((800, 600), True), ((1024, 768), False), ((1920, 1080), False)):
+        assert Renderer(load_scene('scene-dev', size), device=False, seed=0).split_passes is split
