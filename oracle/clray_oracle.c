@@ -935,6 +935,15 @@ static bounce_sample draw_bounce(const orc_rng *g, unsigned pixel, unsigned pass
         const float *L = g->lights + 8 * idx;
         B.light_normal = v3(d.light_dir[0], d.light_dir[1], d.light_dir[2]);
         B.light_point = v3(L[0] + d.light_dir[0] * L[3], L[1] + d.light_dir[1] * L[3], L[2] + d.light_dir[2] * L[3]);
+        if (!(L[3] > 0.0f)) {           /* a box: face records at the float offset in L[7] */
+            int offset;
+            float point[3], normal[3];
+            memcpy(&offset, L + 7, 4);
+            clr_box_light_point(g->lights + offset, d.light_uniforms[2], d.light_uniforms[0], d.light_uniforms[1],
+                                point, normal);
+            B.light_point = v3(point[0], point[1], point[2]);
+            B.light_normal = v3(normal[0], normal[1], normal[2]);
+        }
         B.light_area = L[4];
         B.min_light_sampling_distance = L[5];
         B.light_center = v3(L[0], L[1], L[2]);

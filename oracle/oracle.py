@@ -312,7 +312,7 @@ class OracleScene:
         if getattr(r, 'rng_mode', 'tape') == 'philox':
             lights = np.ascontiguousarray(r.light_table, np.float32)
             rng = Rng(r.rng_seed & 0xffffffff, (r.rng_seed >> 32) & 0xffffffff, int(first_pass),
-                      r.ray_range[0] if r.ray_range else 0, lights.shape[0], _fptr(lights))
+                      r.ray_range[0] if r.ray_range else 0, r.n_lights, _fptr(lights))
             bounces = np.zeros(1, np.float32)
         n = passes.shape[0]
         if img is None:

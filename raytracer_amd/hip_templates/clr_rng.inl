@@ -91,6 +91,7 @@ CLR_MATH_FN void clr_normal_pair(float u1, float u2, float *g0, float *g1) {
  * numbers of clr_draw_segment, which evaluates all of them. */
 typedef struct clr_segment_draw {
     float rvec[3], p, gauss[3], russian, light_u, light_dir[3];
+    float light_uniforms[3];     /* the three uniforms behind light_dir and one more: box lights */
 } clr_segment_draw;
 
 CLR_MATH_FN void clr_draw_block0(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
@@ -112,11 +113,26 @@ CLR_MATH_FN void clr_draw_gauss(unsigned seed_lo, unsigned seed_hi, unsigned pix
 }
 
 CLR_MATH_FN void clr_draw_light(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
-                                unsigned segment, float *light_u, float light_dir[3]) {
+                                unsigned segment, float *light_u, float light_dir[3], float uniforms[3]) {
     unsigned r[4];
     clr_philox4x32(pixel, pass, segment, 2u, seed_lo, seed_hi, r);
     *light_u = clr_u01(r[0]);
-    clr_sphere_direction(clr_u01(r[1]), clr_u01(r[2]), light_dir);
+    uniforms[0] = clr_u01(r[1]); uniforms[1] = clr_u01(r[2]); uniforms[2] = clr_u01(r[3]);
+    clr_sphere_direction(uniforms[0], uniforms[1], light_dir);
+}
+
+/* Point and outward normal on a box light (Parallelepiped.random_surface_point_and_normal).
+ * faces: 6 records of 16 floats = (start corner, share of the total area up to and including this
+ * face), (edge u, 0), (edge v, 0), (outward unit normal, 0); the face is picked by area. */
+CLR_MATH_FN void clr_box_light_point(const float *faces, float pick, float a, float b,
+                                     float point[3], float normal[3]) {
+    int f = 0;
+    while (f < 5 && pick >= faces[16 * f + 3]) f++;
+    const float *F = faces + 16 * f;
+    for (int c = 0; c < 3; ++c) {
+        point[c] = (F[c] + a * F[4 + c]) + b * F[8 + c];
+        normal[c] = F[12 + c];
+    }
 }
 
 CLR_MATH_FN void clr_draw_segment(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
@@ -125,5 +141,6 @@ CLR_MATH_FN void clr_draw_segment(unsigned seed_lo, unsigned seed_hi, unsigned p
     clr_draw_gauss(seed_lo, seed_hi, pixel, pass, segment, d->gauss);
     d->light_u = 0.0f;
     d->light_dir[0] = d->light_dir[1] = 0.0f; d->light_dir[2] = 1.0f;
-    if (with_light) clr_draw_light(seed_lo, seed_hi, pixel, pass, segment, &d->light_u, d->light_dir);
+    d->light_uniforms[0] = d->light_uniforms[1] = d->light_uniforms[2] = 0.0f;
+    if (with_light) clr_draw_light(seed_lo, seed_hi, pixel, pass, segment, &d->light_u, d->light_dir, d->light_uniforms);
 }

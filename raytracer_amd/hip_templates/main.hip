@@ -36,8 +36,9 @@ __constant__ int clr_rng_mode = {{ 1 if renderer.rng_mode == 'philox' else 0 }};
 __constant__ int clr_split_mode = {{ 1 if renderer.split_passes else 0 }};
 #define CLR_LOG_FLOATS {{ 1 + 6*renderer.scene.max_bounces }}   // per (pass, pixel): header word, then <= 2 addends of 3 floats per segment
 ### if renderer.rng_mode == 'philox'
-// next-event lights (spheres): (centre, R), (area, minimum sampling distance, object id bits, 0)
-__constant__ float4 clr_lights[{{ [2*renderer.n_lights, 2]|max }}];
+// next-event lights: per light (centre, R or 0 for a box), (area, minimum sampling distance, object id
+// bits, float offset of the box's face records as int bits); then the face records (clr_rng.inl)
+__constant__ float4 clr_lights[{{ [renderer.light_table.size // 4, 2]|max }}];
 ### endif
 
 {% include 'shader.hip' %}
@@ -183,13 +184,22 @@ CLR_FN BounceSample clr_draw_bounce(const uint seed_lo, const uint seed_hi, cons
     B.light_center = make_vec3(0.0f, 0.0f, 0.0f); B.light_id = 0;
     ### if renderer.n_lights
     if (with_light) {
-        float light_u, light_dir[3];
-        clr_draw_light(seed_lo, seed_hi, pixel, pass, segment, &light_u, light_dir);
+        float light_u, light_dir[3], light_uniforms[3];
+        clr_draw_light(seed_lo, seed_hi, pixel, pass, segment, &light_u, light_dir, light_uniforms);
         int idx = (int)(light_u * {{ renderer.n_lights|float }}f);
         if (idx > {{ renderer.n_lights - 1 }}) idx = {{ renderer.n_lights - 1 }};
         const float4 L0 = clr_lights[2*idx], L1 = clr_lights[2*idx + 1];
         B.light_normal = make_vec3(light_dir[0], light_dir[1], light_dir[2]);
         B.light_point = make_vec3(L0.x + light_dir[0] * L0.w, L0.y + light_dir[1] * L0.w, L0.z + light_dir[2] * L0.w);
+        ### if renderer.has_box_lights
+        if (!(L0.w > 0.0f)) {
+            float point[3], normal[3];
+            clr_box_light_point((const float *)clr_lights + __float_as_int(L1.w), light_uniforms[2],
+                                light_uniforms[0], light_uniforms[1], point, normal);
+            B.light_point = make_vec3(point[0], point[1], point[2]);
+            B.light_normal = make_vec3(normal[0], normal[1], normal[2]);
+        }
+        ### endif
         B.light_area = L1.x;
         B.min_light_sampling_distance = L1.y;
         B.light_center = make_vec3(L0);

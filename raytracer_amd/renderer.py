@@ -124,18 +124,31 @@ class Renderer:
         # RGB material tables (5 float4 + 5 float per object and the ambient medium) are copied to
         # LDS by every block when they are small: 10 kB at most
         self.materials_in_lds = bool(self.shader.rgb) and 5 * (len(self.scene.objects) + 1) <= 512
-        # per-pixel random numbers: the light points are drawn on the device, from this table
-        # (centre, R, area, minimum sampling distance, object id); spheres only
-        self.light_table = np.zeros((self.n_lights, 8), dtype=np.float32)
+        # per-pixel random numbers: the light points are drawn on the device, from this table: per
+        # light 8 floats (centre, R or 0 for a box, area, minimum sampling distance, object id, float
+        # offset of the box's faces), then per box 6 face records of 16 floats (clr_rng.inl)
+        headers = np.zeros((self.n_lights, 8), dtype=np.float32)
+        faces = []
         if self.rng_mode == 'philox':
-            for row, light_id in zip(self.light_table, self.bidirectional_light_ids):
+            for row, light_id in zip(headers, self.bidirectional_light_ids):
                 tracer = self.scene.objects[light_id].tracer
-                if not hasattr(tracer, 'R') or not hasattr(tracer, '_check_no_distortion'):
-                    raise NotImplementedError("rng_mode='philox' samples sphere lights only")
-                tracer._check_no_distortion()
                 center, min_dist = tracer.center_and_min_sampling_distance()
-                row[0:3], row[3], row[4], row[5] = center, tracer.R, tracer.surface_area(), min_dist
+                row[0:3], row[4], row[5] = center, tracer.surface_area(), min_dist
                 row[6:7] = np.array([light_id + 1], dtype=np.int32).view(np.float32)
+                if hasattr(tracer, 'R') and hasattr(tracer, '_check_no_distortion'):
+                    tracer._check_no_distortion()
+                    row[3] = tracer.R
+                elif hasattr(tracer, '_faces'):
+                    offset = headers.size + 16 * len(faces)
+                    row[7:8] = np.array([offset], dtype=np.int32).view(np.float32)
+                    box = tracer._faces()
+                    shares = np.cumsum([f[4] for f in box]) / sum(f[4] for f in box)
+                    for (start, u, v, outward, _), share in zip(box, shares):
+                        faces.append(np.concatenate([start, [share], u, [0], v, [0], outward, [0]]))
+                else:
+                    raise NotImplementedError("rng_mode='philox' samples sphere and box lights only")
+        self.has_box_lights = len(faces) > 0
+        self.light_table = np.concatenate([headers.ravel()] + [np.asarray(f, dtype=np.float32) for f in faces])
 
     def _collect_tracer_data(self):
         """Pack per-object parameters and mesh data (role of reference renderer.py:121-241).

@@ -75,17 +75,18 @@ def test_philox_known_answers_and_sampler_statistics(lib):
         lib.orc_philox4x32(u4(*counter), u2(*key), out)
         assert tuple(out) == want
     lib.orc_rng_segment.argtypes = [ctypes.c_uint] * 5 + [ctypes.POINTER(ctypes.c_float)]
-    buf = (ctypes.c_float * 12)()
+    buf = (ctypes.c_float * 15)()
     draws = []
     for pixel in range(4000):
         lib.orc_rng_segment(7, 9, pixel, pixel % 5, pixel % 3, buf)
         draws.append(list(buf))
-    d = np.array(draws, dtype=np.float64)      # rvec 0:3, p 3, gauss 4:7, russian 7, light_u 8, light_dir 9:12
+    d = np.array(draws, dtype=np.float64)      # rvec 0:3, p 3, gauss 4:7, russian 7, light_u 8, light_dir 9:12, three more uniforms 12:15
     for cols in (slice(0, 3), slice(9, 12)):
         assert np.abs(np.linalg.norm(d[:, cols], axis=1) - 1).max() < 1e-6
         assert np.abs(d[:, cols].mean(axis=0)).max() < 0.04
     assert abs(d[:, 3].mean() - 0.5) < 0.02 and abs(d[:, 7].mean() - 0.5) < 0.02 and abs(d[:, 8].mean() - 0.5) < 0.02
-    assert (d[:, [3, 7, 8]] >= 0).all() and (d[:, [3, 7, 8]] < 1).all()
+    assert (d[:, [3, 7, 8, 12, 13, 14]] >= 0).all() and (d[:, [3, 7, 8, 12, 13, 14]] < 1).all()
+    assert np.abs(d[:, 12:15].mean(axis=0) - 0.5).max() < 0.03
     g = d[:, 4:7]
     assert np.abs(g.mean(axis=0)).max() < 0.06 and np.abs(g.std(axis=0) - 1).max() < 0.05
     assert np.abs(np.corrcoef(g.T) - np.eye(3)).max() < 0.06

@@ -420,6 +420,23 @@ def test_box_light_and_two_lights_bit_exact():
     r.render_samples(12, 384)
     a, b = r.get_image().mean(), plain.get_image().mean()
     assert abs(a - b) < 0.2 * b, (a, b)
+    # per-pixel random numbers: the box is sampled on the device (clr_box_light_point) - HIP equals
+    # the oracle bit for bit, and the converged mean agrees with the tape mode's
+    p = Renderer(build(True), seed=11, rng_mode='philox')
+    assert p.has_box_lights
+    posc = oracle.OracleScene(p)
+    ptape = p.make_tape(0, 1)
+    _, dump = p.render_tape(ptape, debug=True)
+    oimg, odump, _ = posc.render(ptape, debug=True)
+    assert np.array_equal(bits(dump), bits(odump))
+    ptape = p.make_tape(1, 8)
+    p.render_tape(ptape, first_pass=1)
+    oimg, _, _ = posc.render(ptape, img=oimg, first_pass=1)
+    assert np.array_equal(bits(p.img.get()), bits(oimg))
+    p.img.fill(0)
+    p.render_samples(9, 384)
+    c = p.get_image().mean()
+    assert abs(c - b) < 0.2 * b, (c, b)
 
 
 def test_pooled_and_per_lane_triangle_tests_agree_on_a_larger_mesh():
