@@ -29,12 +29,12 @@ FULL_GPU_LANES = 256 * 4 * 6 * 64
 SPLIT_LANES = 4 * FULL_GPU_LANES
 
 
-def pass_groups_for(n_pixels, n_passes):
-    """Lanes per pixel of a pass-split launch: enough for SPLIT_LANES lanes, at most one group per
-    pass, and no more groups than ceil(n_passes / passes per group) can use."""
+def pass_groups_for(n_pixels, n_passes, at_least=1):
+    """Lanes per pixel of a pass-split launch: enough for SPLIT_LANES lanes (and `at_least`), at
+    most one group per pass, and no more groups than ceil(n_passes / passes per group) can use."""
     if n_passes <= 0:
         return 1
-    groups = max(1, min(n_passes, -(-SPLIT_LANES // n_pixels)))
+    groups = max(1, min(n_passes, max(at_least, -(-SPLIT_LANES // n_pixels))))
     per_group = -(-n_passes // groups)
     return -(-n_passes // per_group)
 
@@ -81,7 +81,14 @@ class Renderer:
         # scene-test 320 x 240 32 -> 275 Msamples/s, scene-dev 320 x 240 4.1 -> 11.8 Gsamples/s,
         # 800 x 600 (the reference's default size) 16.8 -> 19.2; at 1080p the log costs a light
         # kernel 11 %, so the default is: on up to 1.5 x the lanes that fill the GPU.
-        self.split_passes = (2 * self.n_pixels <= 3 * FULL_GPU_LANES) if split_passes is None else bool(split_passes)
+        # Scenes with triangle meshes are split at every size, into at least 4 groups: their waves
+        # are long and uneven (a ray that enters the octree costs many times one that misses it), and
+        # shorter waves even that out - scene-mesh 1080p 338 -> 385 Msamples/s, scene-test 1080p
+        # 0.68 -> 1.04 Gsamples/s.  (Ray-marching scenes lose: scene-marchers 4K 1.48 -> 1.29.)
+        self.has_mesh = any(obj.tracer.has_data() for obj in scene.objects)
+        if split_passes is None:
+            split_passes = 2 * self.n_pixels <= 3 * FULL_GPU_LANES or self.has_mesh
+        self.split_passes = bool(split_passes)
         self._pass_log = None
         # optional occupancy hint for the render kernel (second __launch_bounds__ argument)
         self.min_waves_per_simd = min_waves_per_simd
@@ -444,8 +451,8 @@ class Renderer:
         """Render passes [first, first + count) of the resident tape (no host transfer)."""
         assert 0 <= first and first + count <= self._resident_passes
         if self.split_passes:
-            # keep the addend log below 2 GB: longer ranges go as several launches
-            most = max(1, (1 << 31) // ((1 + 6 * self.scene.max_bounces) * self.n_pixels * 4))
+            # keep the addend log below 8 GB: longer ranges go as several launches
+            most = max(1, (1 << 33) // ((1 + 6 * self.scene.max_bounces) * self.n_pixels * 4))
             if count > most:
                 ms = [self.render_resident(f, min(most, first + count - f), stream, timed)
                       for f in range(first, first + count, most)]
@@ -465,7 +472,7 @@ class Renderer:
         """The pass-split fields of clr_render_args (empty for a one-lane-per-pixel program)."""
         if not self.split_passes:
             return {}
-        groups = 1 if debug else pass_groups_for(self.n_pixels, n_passes)
+        groups = 1 if debug else pass_groups_for(self.n_pixels, n_passes, 4 if self.has_mesh else 1)
         floats = 1 + 6 * self.scene.max_bounces
         if self._pass_log is None or self._pass_log.shape[0] < n_passes:
             self._pass_log = None          # release before growing
