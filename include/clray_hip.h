@@ -86,6 +86,8 @@ int clr_launch(clr_program *prog, const char *kernel, const unsigned grid[3],
 /* ---- the hot path: replaces the whole of Renderer.render_sample + compute_next_path_segment
  * (renderer.py:293-433) for `n_passes` consecutive sample passes. */
 typedef struct clr_render_args {
+    size_t struct_size;        /* sizeof(clr_render_args) of the caller's binding: a binding made from
+                                * an older header fails cleanly instead of being read past its end */
     void *img;                 /* n_pixels x float4, running sum per pixel (blocked pixel order) */
     const void *cam;           /* n_pixels x float4, un-jittered primary ray per pixel */
     const void *pass_tape;     /* n_passes x 6 float4: camera sample per pass */

@@ -28,7 +28,7 @@ class DeviceInfo(ctypes.Structure):
 
 
 class RenderArgs(ctypes.Structure):
-    _fields_ = [('img', ctypes.c_void_p), ('cam', ctypes.c_void_p),
+    _fields_ = [('struct_size', ctypes.c_size_t), ('img', ctypes.c_void_p), ('cam', ctypes.c_void_p),
                 ('pass_tape', ctypes.c_void_p), ('bounce_tape', ctypes.c_void_p),
                 ('material_rows', ctypes.c_void_p), ('vector_data', ctypes.c_void_p),
                 ('integer_data', ctypes.c_void_p), ('n_pixels', ctypes.c_int),
@@ -37,6 +37,10 @@ class RenderArgs(ctypes.Structure):
                 ('rng_seed_lo', ctypes.c_uint), ('rng_seed_hi', ctypes.c_uint),
                 ('first_pass', ctypes.c_int), ('first_ray', ctypes.c_int),
                 ('pass_log', ctypes.c_void_p), ('pass_groups', ctypes.c_int)]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.struct_size = ctypes.sizeof(RenderArgs)
 
 
 class OctreeInfo(ctypes.Structure):

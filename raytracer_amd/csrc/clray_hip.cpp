@@ -296,6 +296,10 @@ int clr_launch(clr_program *prog, const char *kernel, const unsigned grid[3],
 
 int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms) {
     if (!prog || !a) return fail("null argument");
+    if (a->struct_size != sizeof(clr_render_args))
+        return fail("clr_render_passes: args->struct_size is " + std::to_string(a->struct_size) +
+                    ", this library's clr_render_args has " + std::to_string(sizeof(clr_render_args)) +
+                    " bytes: the binding was made from another version of clray_hip.h");
     if (int rc = set_device(prog->ctx)) return rc;
     if (!prog->render) return fail("clr_render_passes: the program has no kernel clr_render");
     if (a->n_pixels <= 0 || a->n_passes < 0) return fail("clr_render_passes: bad n_pixels / n_passes");
