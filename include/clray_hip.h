@@ -120,6 +120,18 @@ typedef struct clr_render_args {
 int clr_render_passes(clr_program *prog, const clr_render_args *args, void *stream,
                       float *elapsed_ms);
 
+/* The same call for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * For pass-split programs only: the addend log - the one buffer of the path that is neither input
+ * nor output - lives in a CLR_STATIC_LOG_BYTES array inside the library (one per GPU, held until
+ * the process ends) instead of args->pass_log, which must be NULL.  The call allocates and frees
+ * nothing; it fails when n_passes x (1 + 6 max_bounces) x n_pixels x 4 bytes exceed the array
+ * (render fewer passes per call).  Results equal clr_render_passes bit for bit.  Every call on a
+ * GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race. */
+#define CLR_STATIC_LOG_BYTES (128u << 20)
+int clr_render_passes_static_log(clr_program *prog, const clr_render_args *args, void *stream,
+                                 float *elapsed_ms);
+
 /* First-hit AOV for the primary rays of the first pass record: ids = (object, sub-object) pairs. */
 int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape,
                   const void *vector_data, const void *integer_data, int n_pixels,

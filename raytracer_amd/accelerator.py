@@ -86,6 +86,7 @@ def load_library():
         'clr_launch': (ci, [vp, cp, P(ctypes.c_uint), P(ctypes.c_uint), ci, P(vp), vp,
                             P(ctypes.c_float)]),
         'clr_render_passes': (ci, [vp, P(RenderArgs), vp, P(ctypes.c_float)]),
+        'clr_render_passes_static_log': (ci, [vp, P(RenderArgs), vp, P(ctypes.c_float)]),
         'clr_first_hit': (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
         'clr_octree_build': (ci, [vp, ci, vp, ci, ci, ci, P(vp)]),
         'clr_octree_info': (ci, [vp, P(OctreeInfo)]),
@@ -344,11 +345,11 @@ class Accelerator:
                                    ctypes.byref(ms)))
         self._record(kernel_name, ms.value * 1e-3, time.time() - t0)
 
-    def render_passes(self, args, stream=None, timed=True):
+    def render_passes(self, args, stream=None, timed=True, static_log=False):
         t0 = time.time()
         ms = ctypes.c_float(0)
-        _check(self.lib.clr_render_passes(self.prog, ctypes.byref(args), stream,
-                                          ctypes.byref(ms) if timed else None))
+        entry = self.lib.clr_render_passes_static_log if static_log else self.lib.clr_render_passes
+        _check(entry(self.prog, ctypes.byref(args), stream, ctypes.byref(ms) if timed else None))
         if timed:
             self._record('clr_render', ms.value * 1e-3, time.time() - t0)
         return ms.value

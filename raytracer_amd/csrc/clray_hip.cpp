@@ -1,6 +1,7 @@
 // libclray_hip.so - host side of the MI355X back end (see include/clray_hip.h).
 // Compiles scene-specialised HIP source with hiprtc for gfx950, loads it as a module and
-// launches its kernels.  No device code lives in this file.
+// launches its kernels.  The only device-side object in this file is the static addend log of
+// clr_render_passes_static_log; the kernels are the scene-specialised programs.
 #include "clray_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -9,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,6 +32,26 @@ int check(hipError_t e, const char *what) {
 
 const unsigned kBlock = 256;
 
+// ---- addend log of clr_render_passes_static_log: device memory the library holds from load to
+// exit so that the call itself allocates nothing.  On the host `scratch` is only a handle for
+// hipGetSymbolAddress; kernels get the per-device address kept in g_scratch_ptr.
+static __device__ __align__(256) unsigned char scratch[CLR_STATIC_LOG_BYTES];
+const int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices];
+std::mutex g_scratch_mutex;
+
+// with `device` current: looks up that device's copy of the array once
+int resolve_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return fail("device index beyond the static log table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return 0;
+    void *ptr = nullptr;
+    if (int rc = check(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(static log)")) return rc;
+    if (!ptr) return fail("hipGetSymbolAddress(static log) returned a null address");
+    g_scratch_ptr[device] = ptr;
+    return 0;
+}
+
 }  // namespace
 
 struct clr_ctx {
@@ -43,6 +65,7 @@ struct clr_program {
     hipFunction_t render, first_hit, reduce_log;
     int rng_mode;      // 1: the program draws per-pixel random numbers, 0: it reads the bounce tape
     int split_mode;    // 1: clr_render logs addends per pass and clr_reduce_log sums them
+    int log_floats;    // floats per (pass, pixel) of the addend log (module global clr_log_floats)
 };
 
 namespace {
@@ -109,6 +132,7 @@ int clr_ctx_create(int device_index, clr_ctx **out) {
         return fail("no HIP device available: libclray_hip needs an AMD GPU (gfx950)");
     if (device_index < 0 || device_index >= count) return fail("device index out of range");
     CLR_TRY(hipSetDevice(device_index));
+    if (int rc = resolve_scratch(device_index)) return rc;
     clr_ctx *ctx = new clr_ctx;
     ctx->device = device_index;
     if (int rc = check(hipEventCreate(&ctx->ev_start), "hipEventCreate")) { delete ctx; return rc; }
@@ -224,6 +248,9 @@ int load_program(clr_ctx *ctx, const void *binary, clr_program **out) {
         (void)hipMemcpyDtoH(&prog->rng_mode, flag, sizeof(int));
     if (hipModuleGetGlobal(&flag, &flag_size, prog->module, "clr_split_mode") == hipSuccess && flag_size == sizeof(int))
         (void)hipMemcpyDtoH(&prog->split_mode, flag, sizeof(int));
+    prog->log_floats = 0;
+    if (hipModuleGetGlobal(&flag, &flag_size, prog->module, "clr_log_floats") == hipSuccess && flag_size == sizeof(int))
+        (void)hipMemcpyDtoH(&prog->log_floats, flag, sizeof(int));
     (void)hipGetLastError();
     *out = prog;
     return 0;
@@ -294,7 +321,10 @@ int clr_launch(clr_program *prog, const char *kernel, const unsigned grid[3],
     return launch(prog->ctx, fn, grid, block, args, stream, elapsed_ms);
 }
 
-int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms) {
+namespace {
+// static_log: the addend log is the library's own array (clr_render_passes_static_log)
+int render_passes(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms,
+                  void *static_log) {
     if (!prog || !a) return fail("null argument");
     if (a->struct_size != sizeof(clr_render_args))
         return fail("clr_render_passes: args->struct_size is " + std::to_string(a->struct_size) +
@@ -311,7 +341,20 @@ int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream,
         return fail("clr_render_passes: bounce_tape is required for a tape program");
     if (a->debug_dump && a->n_passes != 1)
         return fail("clr_render_passes: debug_dump needs n_passes == 1");
-    if (prog->split_mode) {
+    if (static_log) {
+        if (!prog->split_mode)
+            return fail("clr_render_passes_static_log: only pass-split programs use a log; call clr_render_passes");
+        if (a->pass_log) return fail("clr_render_passes_static_log: pass_log must be NULL, the log is the library's");
+        if (!prog->reduce_log || prog->log_floats < 1)
+            return fail("clr_render_passes_static_log: the program lacks clr_reduce_log / clr_log_floats");
+        if (a->pass_groups < 1) return fail("clr_render_passes_static_log: pass_groups must be >= 1");
+        const unsigned long long need = 4ull * (unsigned)a->n_passes * (unsigned)prog->log_floats * (unsigned)a->n_pixels;
+        if (need > CLR_STATIC_LOG_BYTES)
+            return fail("clr_render_passes_static_log: the addend log of this call needs " + std::to_string(need) +
+                        " bytes, the static log holds " + std::to_string(CLR_STATIC_LOG_BYTES) +
+                        ": render fewer passes per call");
+    }
+    else if (prog->split_mode) {
         if (!prog->reduce_log) return fail("clr_render_passes: the pass-split program has no kernel clr_reduce_log");
         if (a->pass_groups < 1 || !a->pass_log)
             return fail("clr_render_passes: a pass-split program needs pass_groups >= 1 and a pass_log buffer");
@@ -326,7 +369,9 @@ int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream,
     void *dbg = a->debug_dump;
     unsigned seed_lo = a->rng_seed_lo, seed_hi = a->rng_seed_hi;
     int first_pass = a->first_pass, first_ray = a->first_ray;
-    void *pass_log = a->pass_log;
+    // every (pass, pixel) header of the log and every entry it counts is written by clr_render
+    // before clr_reduce_log reads it, so what an earlier call left in the static array is never seen
+    void *pass_log = static_log ? static_log : a->pass_log;
     int pass_groups = a->pass_groups;
     void *args[] = {&img, &cam, &pt, &bt, &mr, &vd, &id, &n_pixels, &n_passes, &regen, &dbg,
                     &seed_lo, &seed_hi, &first_pass, &first_ray, &pass_log, &pass_groups};
@@ -352,6 +397,19 @@ int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream,
         CLR_TRY(hipEventElapsedTime(elapsed_ms, prog->ctx->ev_start, prog->ctx->ev_stop));
     }
     return 0;
+}
+}  // namespace
+
+int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms) {
+    return render_passes(prog, a, stream, elapsed_ms, nullptr);
+}
+
+int clr_render_passes_static_log(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms) {
+    if (!prog) return fail("null argument");
+    const int device = prog->ctx->device;
+    void *log = device >= 0 && device < kMaxDevices ? g_scratch_ptr[device] : nullptr;
+    if (!log) return fail("clr_render_passes_static_log: the static log of this device was not set up");
+    return render_passes(prog, a, stream, elapsed_ms, log);
 }
 
 int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape, const void *vector_data,

@@ -35,6 +35,7 @@ __constant__ int clr_rng_mode = {{ 1 if renderer.rng_mode == 'philox' else 0 }};
 // read by the host library like clr_rng_mode
 __constant__ int clr_split_mode = {{ 1 if renderer.split_passes else 0 }};
 #define CLR_LOG_FLOATS {{ 1 + 6*renderer.scene.max_bounces }}   // per (pass, pixel): header word, then <= 2 addends of 3 floats per segment
+__constant__ int clr_log_floats = CLR_LOG_FLOATS;              // read by the host library (size check of the static log)
 ### if renderer.rng_mode == 'philox'
 // next-event lights: per light (centre, R or 0 for a box), (area, minimum sampling distance, object id
 // bits, float offset of the box's face records as int bits); then the face records (clr_rng.inl)

@@ -447,10 +447,12 @@ class Renderer:
         self._resident_passes = tape[0].shape[0]
         self._resident_first_pass = int(first_pass)
 
-    def render_resident(self, first, count, stream=None, timed=True):
-        """Render passes [first, first + count) of the resident tape (no host transfer)."""
+    def render_resident(self, first, count, stream=None, timed=True, static_log=False):
+        """Render passes [first, first + count) of the resident tape (no host transfer).
+        static_log: through clr_render_passes_static_log, the entry point that allocates nothing
+        (pass-split programs; the caller keeps `count` within the library's static log)."""
         assert 0 <= first and first + count <= self._resident_passes
-        if self.split_passes:
+        if self.split_passes and not static_log:
             # keep the addend log below 8 GB: longer ranges go as several launches
             most = max(1, (1 << 33) // ((1 + 6 * self.scene.max_bounces) * self.n_pixels * 4))
             if count > most:
@@ -465,14 +467,17 @@ class Renderer:
             material_rows=rows,
             vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
             n_pixels=self.n_pixels, n_passes=count, regenerate=int(self.regenerate),
-            debug_dump=None, **self._split_args(count), **self._rng_args(self._resident_first_pass + first))
-        return self.acc.render_passes(args, stream=stream, timed=timed)
+            debug_dump=None, **self._split_args(count, static_log=static_log),
+            **self._rng_args(self._resident_first_pass + first))
+        return self.acc.render_passes(args, stream=stream, timed=timed, static_log=static_log)
 
-    def _split_args(self, n_passes, debug=False):
+    def _split_args(self, n_passes, debug=False, static_log=False):
         """The pass-split fields of clr_render_args (empty for a one-lane-per-pixel program)."""
         if not self.split_passes:
             return {}
         groups = 1 if debug else pass_groups_for(self.n_pixels, n_passes, 4 if self.has_mesh else 1)
+        if static_log:
+            return dict(pass_log=None, pass_groups=groups)
         floats = 1 + 6 * self.scene.max_bounces
         if self._pass_log is None or self._pass_log.shape[0] < n_passes:
             self._pass_log = None          # release before growing
@@ -485,7 +490,7 @@ class Renderer:
                     rng_seed_lo=self.rng_seed & 0xffffffff, rng_seed_hi=(self.rng_seed >> 32) & 0xffffffff,
                     first_pass=int(first_pass), first_ray=self.ray_range[0] if self.ray_range else 0)
 
-    def render_tape(self, tape, debug=False, stream=None, timed=True, first_pass=0):
+    def render_tape(self, tape, debug=False, stream=None, timed=True, first_pass=0, static_log=False):
         """Render the passes described by `tape` and add them to the image accumulator.
         Returns (kernel milliseconds, debug dump or None)."""
         n = tape[0].shape[0]
@@ -500,8 +505,9 @@ class Renderer:
             material_rows=self.dev_rows.ptr if self.dev_rows is not None else None,
             vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
             n_pixels=self.n_pixels, n_passes=n, regenerate=int(self.regenerate),
-            debug_dump=dump.ptr if dump is not None else None, **self._split_args(n, debug), **self._rng_args(first_pass))
-        ms = self.acc.render_passes(args, stream=stream, timed=timed)
+            debug_dump=dump.ptr if dump is not None else None, **self._split_args(n, debug, static_log),
+            **self._rng_args(first_pass))
+        ms = self.acc.render_passes(args, stream=stream, timed=timed, static_log=static_log)
         return ms, (dump.get() if dump is not None else None)
 
     def render_samples(self, first_pass, n_passes):

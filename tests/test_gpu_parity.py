@@ -536,12 +536,12 @@ def test_pass_split_arguments_must_match_the_program():
     r = Renderer(load_scene('scene-dev', (1920, 1080)), seed=0)
     assert not r.split_passes
     tape = r.make_tape(0, 1)
-    r._split_args = lambda n, debug=False: dict(pass_log=r.img.ptr, pass_groups=2)
+    r._split_args = lambda n, debug=False, static_log=False: dict(pass_log=r.img.ptr, pass_groups=2)
     with pytest.raises(Exception) as err:
         r.render_tape(tape)
     assert 'pass-split' in str(err.value)
     small = Renderer(load_scene('scene-dev', (32, 16)), seed=0)
-    small._split_args = lambda n, debug=False: {}
+    small._split_args = lambda n, debug=False, static_log=False: {}
     with pytest.raises(Exception) as err:
         small.render_tape(small.make_tape(0, 1))
     assert 'pass_log' in str(err.value)
