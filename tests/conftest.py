@@ -22,13 +22,16 @@ def load_scene(name, size=None, **overrides):
         scene = runpy.run_path(os.path.join(SCENE_DIR, 'scene-dev.py'))['make_scene'](spectral=True)
     elif name == 'scene-stairs-small':     # 12 of the 65 steps: same classes, quicker to compile
         scene = runpy.run_path(os.path.join(SCENE_DIR, 'scene-stairs.py'))['make_scene'](12)
-    elif name.startswith('variant-'):
+    elif name.startswith('variant-') or name.startswith('spectral-'):
         import types
         import golden_scenes
         from raytracer_amd import objects as shapes
-        from raytracer_amd.scenes.default_scenes import BoxScene
-        api = types.SimpleNamespace(BoxScene=BoxScene, Sphere=shapes.Sphere, Cylinder=shapes.Cylinder,
-                                    HalfSpace=shapes.HalfSpace)
+        from raytracer_amd.geometry import Affine
+        from raytracer_amd.shading import SpectrumShader
+        from raytracer_amd.scenes.default_scenes import BoxScene, DefaultScene
+        api = types.SimpleNamespace(BoxScene=BoxScene, DefaultScene=DefaultScene, SpectrumShader=SpectrumShader,
+                                    Affine=Affine, Cube=shapes.Cube, Sphere=shapes.Sphere,
+                                    Cylinder=shapes.Cylinder, HalfSpace=shapes.HalfSpace)
         scene = golden_scenes.VARIANTS[name](api)
     elif name.startswith('scene-mesh'):      # 'scene-mesh:<n_u>x<n_v>:<layout>', layout 'flat-lanes' = flat, not pooled
         _, grid, layout = (name.split(':') + ['120x60', 'flat'])[:3] if ':' in name else (name, '120x60', 'flat')

@@ -45,4 +45,63 @@ def variant_media(api):
     return s
 
 
-VARIANTS = {'variant-camera': variant_camera, 'variant-media': variant_media}
+def spectral_dev(api):
+    """scene-dev with the spectral shader and materials, i.e. the two lines the reference's
+    scene-dev.py has commented out (scenes/scene-dev.py:3-6), plus a dispersive glass ball so
+    that the wavelength-dependent index of refraction is on the path."""
+    s = api.BoxScene(api.SpectrumShader)
+    for wall in s.get_objects('wall'):
+        wall.material = 'red'
+    s.get_object('floor').material = 'white'
+    s.get_object('ceiling').material = 'green'
+    s.get_object('light').bidirectional_light = True
+    s.materials['black'] = {'diffuse': 0.2}
+    s.materials['light']['diffuse'] = 0.0
+    s.add_object(api.HalfSpace((-1, -1, -2), 5), 'sky')
+    egg = api.Sphere((0, 0, 0.6), 0.3)
+    egg.linear_transform(scaling=(1, 1, 2))
+    s.add_object(egg, 'mirror')
+    s.add_object(api.Sphere((-0.9, -0.6, 0.35), 0.35), 'glass')
+    s.add_object(api.Sphere((0.9, -0.2, 0.3), 0.3), 'wax')
+    s.camera_position = (-2, -3, 1)
+    s.direct_camera_towards((0, 0, 0.6))
+    s.camera_fov = 50
+    s.min_bounces = 2
+    s.max_bounces = 5
+    return s
+
+
+def spectral_stairs(api, n_steps=12):
+    """The first steps of the reference's only spectral scene (scenes/scene-stairs.py:8-60):
+    dome as root object, depth of field, glass / red / light cubes under a chain of affine maps."""
+    class DomeScene(api.DefaultScene):
+        def set_up_objects_and_camera(self):
+            self.materials['dome'] = {'diffuse': 0.0}
+            self.materials['red'] = {'diffuse': self.spectrum.gaussian(670, 30) * 0.9 + 0.05,
+                                     'reflection': 0.1, 'reflection_blur': 0.05}
+            dome = self.add_object(api.Sphere((0, 0, 0), 100), 'dome', 'dome')
+            self.add_object(api.HalfSpace((0, 0, -1), 70.0), 'sky', 'sky')
+            self.add_object(api.HalfSpace((0, 0, 1), 0.0), 'white', 'floor')
+            self.root_object = dome
+            self.camera_position = (1.5, -7.5, 1.5)
+            self.direct_camera_towards((-0.5, 0, 1.5))
+
+    s = DomeScene(api.SpectrumShader)
+    s.camera_dof_fstop = 0.05
+    step_pose = api.Affine(translation=(1, 0, 0))
+    ball_pose = api.Affine(translation=(0, 1.5, 0))
+    advance = api.Affine(rotation_axis=(-0.5, -1, 3.1), rotation_deg=10, translation=(0, 0, 0.07))
+    for j in range(n_steps):
+        step = api.Cube((0, 0, 0), 1.0)
+        step.coordinates = step_pose * api.Affine(scaling=(0.5, 0.2, 0.02))
+        s.add_object(step, {8: 'light', 0: 'red'}.get(j % 16, 'glass'))
+        ball = api.Sphere((0, 0, 0), 0.1)
+        ball.coordinates = ball_pose
+        s.add_object(ball, 'red')
+        step_pose = advance * step_pose
+        ball_pose = advance * ball_pose
+    return s
+
+
+VARIANTS = {'variant-camera': variant_camera, 'variant-media': variant_media,
+            'spectral-dev': spectral_dev, 'spectral-stairs': spectral_stairs}

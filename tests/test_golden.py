@@ -20,7 +20,10 @@ import pytest
 from raytracer_amd.renderer import Renderer
 from conftest import load_scene, GOLDEN_DIR
 
-SCENES = ['scene-dev', 'scene-three-objects', 'scene-test', 'variant-camera', 'variant-media']
+# spectral-*: SpectrumShader scenes; the reference ran them from this package's CIE table written
+# into its data/ directory (tools/make_golden.py), everything after the table is its own code
+SPECTRAL = ['spectral-dev', 'spectral-stairs']
+SCENES = ['scene-dev', 'scene-three-objects', 'scene-test', 'variant-camera', 'variant-media'] + SPECTRAL
 
 
 def golden(name):
@@ -39,6 +42,11 @@ def class_prefix(kernel_name):
     return re.sub(r'\d{4,}', '#', str(kernel_name))
 
 
+def rows_of(fx, passes=slice(None)):
+    """Material rows of the recorded passes (spectral fixtures), else None."""
+    return fx['material_rows'][passes] if 'material_rows' in fx.files else None
+
+
 def near(a, b, tol=1e-4):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
@@ -54,8 +62,15 @@ def test_packing_matches_reference(name):
     assert np.array_equal(r.host_cam, fx['cam'])                      # bit-exact camera rays
     assert r.root_object_id == int(fx['root_object_id'])
     assert list(r.bidirectional_light_ids) == list(fx['bidirectional_light_ids'])
-    assert np.array_equal(r.material_colors, fx['material_colors'])
-    assert np.array_equal(r.material_scalars, np.ravel(fx['material_scalars']))
+    if r.shader.rgb:
+        assert np.array_equal(r.material_colors, fx['material_colors'])
+        assert np.array_equal(r.material_scalars, np.ravel(fx['material_scalars']))
+    else:
+        # SpectrumShader.initialize_material_buffers (shader.py:148-171), Spectrum (spectrum.py:37-56)
+        assert np.array_equal(r.shader.host_mat_y, fx['spectral_host_mat_y'])
+        assert np.array_equal(r.scene.spectrum.wavelengths, fx['spectral_wavelengths'])
+        assert np.array_equal(r.shader.color_responses, fx['spectral_color_responses'])
+        assert np.array_equal(r.shader.color_intensity_pdf, fx['spectral_intensity_pdf'])
     # inverse affine = the last four float3 parameters of every object in the reference's buffers
     offsets = fx['param_int'][int(fx['data_pointer_offset']):].reshape(-1, 5)
     f3 = fx['param_float3']
@@ -75,9 +90,16 @@ def test_tape_generator_reproduces_reference_draw_order(name):
     r = make(name, fx)
     # segments the reference executed per pass (it stops drawing once every ray is dead)
     executed = (np.abs(fx['bounce_tape'][:, :, 0, :3]).sum(axis=-1) > 0).sum(axis=1)
-    passes, bounces, _ = r.make_tape(0, int(fx['n_passes']), segments=executed)
+    passes, bounces, rows = r.make_tape(0, int(fx['n_passes']), segments=executed)
     assert np.array_equal(passes, fx['pass_tape'])
     assert np.array_equal(bounces.view(np.uint32), fx['bounce_tape'].view(np.uint32))
+    if name in SPECTRAL:
+        # SpectrumShader.init_sample (shader.py:173-194): wavelength by inverse cdf, 1 / pdf in
+        # pass_tape[:, 4, 3], colour mask in pass_tape[:, 5], material row at that wavelength
+        assert np.array_equal(rows.view(np.uint32), fx['material_rows'].view(np.uint32))
+        assert (fx['pass_tape'][:, 4, 3] > 1.0).all() and (np.abs(fx['pass_tape'][:, 5, :3]).sum(axis=1) > 0).all()
+    else:
+        assert rows is None
 
 
 def flat_octree_ids(r):
@@ -98,7 +120,7 @@ def test_oracle_segment_state_matches_reference(name):
     fx = golden(name)
     r = make(name, fx)
     osc = oracle.OracleScene(r)
-    tape = (fx['pass_tape'][:1], fx['bounce_tape'][:1], None)
+    tape = (fx['pass_tape'][:1], fx['bounce_tape'][:1], rows_of(fx, slice(0, 1)))
     img, dump, _ = osc.render(tape, debug=True)
     n_segments = int(fx['n_segments'])
     last = r.scene.max_bounces - 1
@@ -134,7 +156,8 @@ def test_oracle_segment_state_matches_reference(name):
         assert np.array_equal(ints[:, 3], ref('diffusions_left').astype(np.int32))
         assert near(d[:, 2, :3], ref('pos')[:, :3]).all()
         assert near(d[:, 3, :3], ref('ray')[:, :3]).all()
-        assert near(d[:, 5, :3], ref('raycolor')[:, :3]).all()
+        ray_color = ref('raycolor')
+        assert near(d[:, 5, :3], ray_color[:, :3] if ray_color.ndim == 2 else ray_color[:, None]).all()
         # the refraction stage stores a flipped normal back; compare up to sign
         n, n_ref = d[:, 4, :3], ref('normal')[:, :3]
         assert (near(n, n_ref).all(axis=1) | near(n, -n_ref).all(axis=1)).all()
@@ -163,7 +186,8 @@ def test_oracle_image_matches_reference(name):
     img = np.zeros((r.n_pixels, 4), np.float32)
     tainted = np.zeros(r.n_pixels, bool)
     for j in range(n_passes):       # pass by pass, to learn which paths touched a flat octree
-        img, dump, _ = osc.render((fx['pass_tape'][j:j + 1], fx['bounce_tape'][j:j + 1], None), img=img, debug=True)
+        img, dump, _ = osc.render((fx['pass_tape'][j:j + 1], fx['bounce_tape'][j:j + 1], rows_of(fx, slice(j, j + 1))),
+                                  img=img, debug=True)
         tainted |= np.isin(dump[:, :, 0, 0].view(np.int32), flat_octree_ids(r)).any(axis=0)
     assert tainted.mean() < 0.03
     ref = fx['img'][~tainted, :3].astype(np.float64)
@@ -173,7 +197,7 @@ def test_oracle_image_matches_reference(name):
         assert rmse <= 1e-4 * max(np.sqrt(np.mean(ref[:, c] ** 2)), 1e-12), (c, rmse)
     assert near(got, ref, 1e-4).all()
     # one launch over all passes gives the same sums as pass-by-pass accumulation
-    whole, _, _ = osc.render((fx['pass_tape'], fx['bounce_tape'], None))
+    whole, _, _ = osc.render((fx['pass_tape'], fx['bounce_tape'], rows_of(fx)))
     assert np.array_equal(whole.view(np.uint32), img.view(np.uint32))
 
 

@@ -214,18 +214,18 @@ def test_bad_arguments_are_rejected():
         r.acc.render_passes(RenderArgs(n_pixels=10, n_passes=1))
 
 
-@pytest.mark.parametrize('name', SCENES + ['variant-camera', 'variant-media'])
+@pytest.mark.parametrize('name', SCENES + ['variant-camera', 'variant-media', 'spectral-dev', 'spectral-stairs'])
 def test_hip_against_reference_golden(name):
     """HIP directly against the fixtures made from the reference's own device code
     (tests/test_golden.py explains the fixtures and the bars)."""
     import os
     from conftest import GOLDEN_DIR
-    from test_golden import flat_octree_ids, near
+    from test_golden import flat_octree_ids, near, rows_of
     fx = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
     size = tuple(int(v) for v in fx['size'])
     r = Renderer(load_scene(name, size, samples_per_pixel=4), seed=int(fx['seed']))
     assert np.array_equal(r.host_cam, fx['cam'])
-    tape = (fx['pass_tape'][:1], fx['bounce_tape'][:1], None)
+    tape = (fx['pass_tape'][:1], fx['bounce_tape'][:1], rows_of(fx, slice(0, 1)))
     ids, t, normal = r.first_hit(tape)
     pixel = fx['seg0_pixel'].astype(np.int64)
     post = fx['seg0_whichobject'].astype(np.int32)
@@ -238,7 +238,8 @@ def test_hip_against_reference_golden(name):
     img = np.zeros((r.n_pixels, 4), np.float32)
     tainted = np.zeros(r.n_pixels, bool)
     for j in range(int(fx['n_passes'])):
-        _, dump = r.render_tape((fx['pass_tape'][j:j + 1], fx['bounce_tape'][j:j + 1], None), debug=True)
+        _, dump = r.render_tape((fx['pass_tape'][j:j + 1], fx['bounce_tape'][j:j + 1], rows_of(fx, slice(j, j + 1))),
+                                debug=True)
         tainted |= np.isin(dump[:, :, 0, 0].view(np.int32), flat_octree_ids(r)).any(axis=0)
     img = r.img.get()
     ref = fx['img'][~tainted, :3].astype(np.float64)

@@ -125,10 +125,32 @@ def prepare_reference():
     open(os.path.join(REF3, '.converted'), 'w').write('ok')
 
 
+def write_cie_table():
+    """The reference reads the CIE 1931 colour matching functions from data/cie-1931.csv, a file
+    it does not ship.  The temporary copy gets this package's table (the analytic
+    fit in raytracer_amd/shading.py, on the 1 nm grid) in the format spectrum.py:40 expects:
+    wavelength, x, y, z per line.  Everything downstream of the table is then the reference's
+    own code: Spectrum.cie_1931_rgb / visible_intensity, SpectrumShader.initialize_material_buffers
+    and init_sample (shader.py:148-194)."""
+    sys.path.insert(0, ROOT)
+    from raytracer_amd.shading import cie_1931_xyz_fit
+    w = np.arange(360, 831, dtype=float)
+    table = np.column_stack((w, cie_1931_xyz_fit(w).T))
+    os.makedirs(os.path.join(REF3, 'data'), exist_ok=True)
+    np.savetxt(os.path.join(REF3, 'data', 'cie-1931.csv'), table, delimiter=',', fmt='%.17g')
+
+
 class HostArray(np.ndarray):
-    """numpy array with the two pyopencl Array methods the reference uses."""
+    """numpy array with the pyopencl Array methods the reference uses."""
     def get(self):
         return np.array(self)
+
+    def __imul__(self, other):
+        # pyopencl multiplies an Array by a host-side operand as by a scalar (shader.py:184 passes
+        # a one-element array); the array holds 1.0 at that point, so the rounding is float32(other)
+        if not isinstance(other, HostArray) and np.size(other) == 1:
+            other = self.dtype.type(np.ravel(other)[0])
+        return np.ndarray.__imul__(self, other)
 
 
 def as_host(a):
@@ -254,6 +276,8 @@ class FakeAccelerator:
 
 def import_reference():
     prepare_reference()
+    write_cie_table()
+    os.chdir(REF3)                               # spectrum.py:40 opens data/cie-1931.csv relative to the cwd
     for p in (REF3, os.path.join(REF3, 'objects'), os.path.join(REF3, 'scenes')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -273,8 +297,13 @@ def make_fixture(scene_name, size, n_passes, seed):
     if scene_name in golden_scenes.VARIANTS:
         import types as _types
         import objects as ref_objects
-        from scenes.default_scenes import BoxScene as RefBoxScene
-        api = _types.SimpleNamespace(BoxScene=RefBoxScene, Sphere=ref_objects.Sphere,
+        import shader as ref_shader
+        import transformations as ref_transformations
+        from scenes.default_scenes import BoxScene as RefBoxScene, DefaultScene as RefDefaultScene
+        api = _types.SimpleNamespace(BoxScene=RefBoxScene, DefaultScene=RefDefaultScene,
+                                     SpectrumShader=ref_shader.SpectrumShader,
+                                     Affine=ref_transformations.Affine, Cube=ref_objects.Cube,
+                                     Sphere=ref_objects.Sphere,
                                      Cylinder=ref_objects.Cylinder, HalfSpace=ref_objects.HalfSpace)
         scene = golden_scenes.VARIANTS[scene_name](api)
     else:
@@ -295,12 +324,24 @@ def make_fixture(scene_name, size, n_passes, seed):
         'root_object_id': np.array(r.root_object_id),
         'bidirectional_light_ids': np.array(r.bidirectional_light_ids),
         'data_pointer_offset': np.array(r.object_data_pointer_buffer_offset),
-        'material_colors': np.array(r.shader.material_buffers[0]),
-        'material_scalars': np.array(r.shader.material_buffers[1]),
         'patch': np.array('culler: float max_value = cur_intensity (SURVEY F12); '
                           'ConvexIntersection.cl: running sub-object offset kept in a jinja2 '
                           'namespace (pre-2.9 loop scoping)'),
     }
+    spectral = not r.shader.rgb
+    if spectral:
+        # host tables of SpectrumShader.initialize_material_buffers (shader.py:148-171), made by
+        # the reference from the injected CIE table
+        fx['spectral_host_mat_y'] = np.array(r.shader.host_mat_y)
+        fx['spectral_color_responses'] = np.array(r.shader.color_responses)
+        fx['spectral_intensity_pdf'] = np.array(r.shader.color_intensity_pdf)
+        fx['spectral_wavelengths'] = np.array(scene.spectrum.wavelengths)
+        fx['cie_table'] = np.array('CIE 1931 table: raytracer_amd.shading.cie_1931_xyz_fit on 360..830 nm, '
+                                   'written to data/cie-1931.csv of the temporary copy (the reference ships none)')
+        material_rows = np.zeros((n_passes, r.shader.host_mat_y.shape[0]), np.float32)
+    else:
+        fx['material_colors'] = np.array(r.shader.material_buffers[0])
+        fx['material_scalars'] = np.array(r.shader.material_buffers[1])
     for key, buf in zip(['vector', 'integer'], r.tracer_data_buffers):
         if buf is not None:
             fx['data_' + key] = np.array(buf)
@@ -338,6 +379,18 @@ def make_fixture(scene_name, size, n_passes, seed):
             bounce_tape[j, b, 1, 3] = value_args[0]
     acc.hooks.append(hook)
 
+    if spectral:
+        # per pass: what SpectrumShader.init_sample (shader.py:173-194) left on the "device"
+        original_init_sample = r.shader.init_sample
+
+        def init_sample(renderer):
+            original_init_sample(renderer)
+            j = state['pass']
+            material_rows[j] = np.ravel(np.array(r.shader.device_material_buffer))
+            pass_tape[j, 4, 3] = np.array(r.ray_state.raycolor)[0]          # 1 / pdf(wavelength)
+            pass_tape[j, 5, 0:3] = r.vec_param_buf[2, :3]                    # colour mask
+        r.shader.init_sample = init_sample
+
     # ---- wrap the per-segment method to snapshot the ray state of pass 0
     original = r.compute_next_path_segment
 
@@ -372,6 +425,8 @@ def make_fixture(scene_name, size, n_passes, seed):
         r.render_sample(j)
         images.append(np.array(r.img))
     fx['pass_tape'], fx['bounce_tape'] = pass_tape, bounce_tape
+    if spectral:
+        fx['material_rows'] = material_rows
     fx['img_after_first_pass'] = images[0]
     fx['img'] = images[-1]
     fx['n_segments'] = np.array(len(snapshots))
@@ -383,7 +438,8 @@ def make_fixture(scene_name, size, n_passes, seed):
 
 
 def main():
-    names = sys.argv[1:] or ['scene-dev', 'scene-three-objects', 'scene-test', 'variant-camera', 'variant-media']
+    names = sys.argv[1:] or ['scene-dev', 'scene-three-objects', 'scene-test', 'variant-camera', 'variant-media',
+                             'spectral-dev', 'spectral-stairs']
     os.makedirs(OUT, exist_ok=True)
     for name in names:
         size = (64, 48) if name != 'scene-test' else (64, 48)
