@@ -12,6 +12,7 @@ is fixed, so scaling is "weak".  Rank 0 prints one JSON line.
 """
 import argparse
 import json
+import math
 import os
 import runpy
 import sys
@@ -23,9 +24,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
-PEAK_FP32_VECTOR_TFLOPS = 157.3        # packed v_pk_fma_f32 (= the dense FP32 MFMA peak)
-PEAK_FP32_SCALAR_FMA_TFLOPS = 78.6     # one v_fma_f32 per lane per issue
+PEAK_FP32_VECTOR_TFLOPS = 157.3        # FP32 vector peak: one v_fma_f32 (2 flop) per lane per clock
+PEAK_FP32_NON_FMA_TOPS = 78.6          # ceiling for code without FMAs (one op per lane per clock): the
+                                       # parity build is compiled with -ffp-contract=off
 PEAK_HBM_GBS = 8000.0                  # HBM3E spec; ~6300 achievable (same guide)
+# algorithmic work is counted by the oracle's instrumented build over ALL timed passes, on every
+# FLOP_PIXEL_STRIDE-th pixel or sparser (a stride coprime to the 32-pixel blocks of the ray order)
+FLOP_COUNT_SAMPLES = 48e6
+# passes the random tape always holds, so that qdirs and the draws of the timed passes do not
+# depend on --steps / --warmup (the timed passes come first, warm-up passes after them)
+TAPE_SAMPLES_PER_PIXEL = 4096
 
 
 def parse_args():
@@ -59,32 +67,46 @@ def parse_args():
     return ap.parse_args()
 
 
-def tiles_requested(args, world):
-    return args.partition == 'tiles' and world > 1
-
-
 def stripe(tape, rank, world):
-    return tuple(x[rank::world] if x is not None else None for x in tape)
+    from raytracer_amd.multi_gpu import stripe as _stripe
+    return _stripe(tape, rank, world)
 
 
-def cpu_baseline(renderer, tape, target_seconds):
+def host_threads():
+    """Threads for the CPU baseline: every core this process may run on (its affinity mask, which
+    on the GPU box is the 16-CPU share of one GPU; OMP_NUM_THREADS is set to the same there)."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    asked = int(os.environ.get('OMP_NUM_THREADS', 0))
+    return max(1, min(allowed, asked) if asked else allowed)
+
+
+def cpu_baseline(renderer, tape, target_seconds, n_timed, first_pass=0):
     """Time the CPU oracle ("port") on a bounded sample of the same workload and count the
-    algorithmic FP32 operations per sample with its instrumented build."""
+    algorithmic FP32 operations per sample with its instrumented build: over the `n_timed`
+    passes the GPU was timed on, on a pixel subsample (tape mode: a pixel's work depends on its
+    camera ray and the shared tape only) or, with per-pixel random numbers, on whole frames of as
+    many of those passes as FLOP_COUNT_SAMPLES allows."""
     from oracle import oracle
     osc = oracle.OracleScene(renderer)
-    threads = int(os.environ.get('OMP_NUM_THREADS', 0)) or min(os.cpu_count() or 1, 16)
+    threads = host_threads()
     one = tuple(x[:1] if x is not None else None for x in tape)
-    # algorithmic work per sample: counted over a few passes, because with the broadcast tape all
-    # pixels of a pass share their random directions and single passes differ by a factor of two
-    n_count = min(4, tape[0].shape[0])
-    flops = mesh_bytes = 0.0
-    for j in range(n_count):
-        single = tuple(x[j:j + 1] if x is not None else None for x in tape)
-        _, _, f = osc.render(single, n_threads=threads, count_flops=True)
-        flops += f
-        mesh_bytes += osc.last_mesh_bytes
-    flops_per_sample = flops / (renderer.n_pixels * n_count)
-    mesh_bytes_per_sample = mesh_bytes / (renderer.n_pixels * n_count)
+    timed = tuple(x[:n_timed] if x is not None else None for x in tape)
+    if renderer.rng_mode == 'tape':
+        stride = int(max(1, -(-renderer.n_pixels * n_timed // FLOP_COUNT_SAMPLES))) | 1
+        while math.gcd(stride, 32) != 1 or (renderer.n_pixels // 32) % stride == 0 and stride > 1:
+            stride += 2
+        pixels = np.arange(0, renderer.n_pixels, stride)
+        _, _, flops = osc.render(timed, n_threads=threads, count_flops=True, pixels=pixels)
+        counted = len(pixels) * n_timed
+        counted_text = 'all %d timed passes, every %d-th pixel' % (n_timed, stride)
+    else:
+        n_count = int(max(1, min(n_timed, FLOP_COUNT_SAMPLES // renderer.n_pixels)))
+        some = tuple(x[:n_count] if x is not None else None for x in tape)
+        _, _, flops = osc.render(some, n_threads=threads, count_flops=True, first_pass=first_pass)
+        counted = renderer.n_pixels * n_count
+        counted_text = 'the first %d timed passes, every pixel' % n_count
+    flops_per_sample = flops / counted
+    mesh_bytes_per_sample = osc.last_mesh_bytes / counted
     t0 = time.time()
     osc.render(one, n_threads=threads)
     t_one = time.time() - t0
@@ -95,10 +117,12 @@ def cpu_baseline(renderer, tape, target_seconds):
     dt = time.time() - t0
     return {
         'value': renderer.n_pixels * n / dt / 1e6, 'unit': 'Msamples/s', 'cores': threads,
-        'kind': 'port',
-        'sample': '%d sample passes of the same %dx%d frame, same tape (%.1f s of CPU work)'
-                  % (n, renderer.img_shape[1], renderer.img_shape[0], dt),
-    }, flops_per_sample, mesh_bytes_per_sample
+        'kind': 'port', 'host_cpus': os.cpu_count(),
+        'cpus_allowed': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
+        'sample': '%d sample passes of the same %dx%d frame, same tape (%.1f s of CPU work on %d threads = '
+                  'every CPU this process may use)'
+                  % (n, renderer.img_shape[1], renderer.img_shape[0], dt, threads),
+    }, flops_per_sample, mesh_bytes_per_sample, counted_text
 
 
 def main():
@@ -130,43 +154,41 @@ def main():
         else:
             scene = runpy.run_path(path)['scene']
         scene.image.size = (width, height)
-        scene.samples_per_pixel = (args.steps + args.warmup) * args.passes_per_step * world
+        scene.samples_per_pixel = max(TAPE_SAMPLES_PER_PIXEL, (args.steps + args.warmup) * args.passes_per_step * world)
         return scene
     scene = load_scene()
 
-    ray_range = None
-    if args.partition == 'tiles' and world > 1:
-        per_rank = -(-(width * height) // world // 256) * 256      # whole blocks of 256 rays
-        first = min(rank * per_rank, width * height)
-        ray_range = (first, max(min(per_rank, width * height - first), 256))
+    from raytracer_amd.multi_gpu import Shard
+    shard = Shard(args.partition, rank, world, width * height)
+    tiles = shard.tiles
     hint = int(args.occupancy_hint) if args.occupancy_hint.isdigit() else None
-    r = Renderer(scene, seed=args.seed, device_index=local_rank, ray_range=ray_range,
+    r = Renderer(scene, seed=args.seed, device_index=local_rank,
                  min_waves_per_simd=hint, rng_mode=args.rng,
                  build_options=args.build_options.split() if args.build_options else None,
                  bake_parameters=None if args.bake is None else bool(args.bake),
-                 split_passes=None if args.split_passes is None else bool(args.split_passes))
+                 split_passes=None if args.split_passes is None else bool(args.split_passes),
+                 **shard.renderer_arguments())
+    shard.configure(r)                          # per-pixel random numbers are keyed by the GLOBAL pass index
     if args.regenerate is not None:
         r.regenerate = bool(args.regenerate)
-    if args.rng == 'philox' and not tiles_requested(args, world):
-        # pass-striped ranks count their passes locally: give every rank its own streams
-        r.rng_seed ^= (rank * 0xD1342543DE82EF95) & (2**64 - 1)
     if args.occupancy_hint == 'auto':
         r.tune_occupancy()                      # part of the program build, outside the timed region
         if rank == 0:
             print('occupancy tuning (ms per hint):', {str(k): round(v, 3) for k, v in r.occupancy_timings.items()},
-                  file=sys.stderr)
-    tiles = ray_range is not None
-    frame = torch.zeros((width * height, 4), dtype=torch.float32, device='cuda')
-    img = frame[ray_range[0]:ray_range[0] + ray_range[1]] if tiles else frame
+                  'scratch bytes per lane:', r.occupancy_scratch, file=sys.stderr)
+    frame = torch.zeros((shard.frame_rows, 4), dtype=torch.float32, device='cuda')
+    img = shard.my_rows(frame)[:r.n_pixels]
     r.use_image_buffer(img.data_ptr())
+    host_frame = torch.empty((width * height, 4), dtype=torch.float32).pin_memory() if rank == 0 else None
 
-    # one global tape (same seed on every rank); rank g renders passes g, g+N, g+2N, ...
+    # One global sequence of passes, drawn from the same seed on every rank: the timed passes first,
+    # the warm-up passes after them, so that the timed work does not depend on --warmup.  With the
+    # passes partition rank g renders passes g, g + N, g + 2N, ... of it.
     P = args.passes_per_step
+    n_timed = args.steps * P
     total = (args.steps + args.warmup) * P * (1 if tiles else world)
-    tape = r.make_tape(0, total)
-    if not tiles:
-        tape = stripe(tape, rank, world)
-    r.upload_tape(tape)
+    tape = shard.local_tape(r.make_tape(0, total))
+    r.upload_tape(tape, first_pass=shard.pass_offset)
 
     def sync():
         torch.cuda.synchronize()
@@ -174,20 +196,26 @@ def main():
             dist.barrier()
 
     for w in range(args.warmup):
-        r.render_resident(w * P, P)
+        r.render_resident(n_timed + w * P, P)
     if use_dist:
         warm = frame.clone()
-        dist.all_reduce(warm)          # set up the communicator outside the timed region
+        shard.combine(warm, dist)      # set up the communicator outside the timed region
+        if world == 1:
+            dist.all_reduce(warm)
     frame.zero_()
     sync()
     t0 = time.perf_counter()
-    kernel_ms = []
+    # the launches go out back to back; one HIP event pair on their stream brackets all of them
+    r.acc.timer_begin()
     for k in range(args.steps):
-        kernel_ms.append(r.render_resident((args.warmup + k) * P, P))
-    if use_dist:
-        dist.all_reduce(frame)         # sum of private accumulators / gather of disjoint tiles
+        r.render_resident(k * P, P, timed=False)
+    kernel_ms_total = r.acc.timer_end(wait=False)
+    shard.combine(frame, dist)         # passes: all-reduce of the private sums; tiles: all-gather
+    if rank == 0:
+        host_frame.copy_(frame[:width * height], non_blocking=True)     # the image goes back to the host
     sync()
     elapsed = time.perf_counter() - t0
+    kernel_ms = [kernel_ms_total() / args.steps]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -213,8 +241,11 @@ def main():
                    'parallelism': ('%s x%d, one all-reduce' % ('tile-partitioned' if tiles else 'pass-striped', world))
                                   if world > 1 else 'single GPU'},
     }
+    result['config']['timed_samples_per_pixel'] = n_timed * (1 if tiles else world)
+    result['config']['timed_region'] = ('%d launches back to back, the exchange step, the copy of the image to '
+                                        'host memory' % args.steps)
     if rank == 0:
-        final = frame.cpu().numpy()
+        final = host_frame.numpy()
         assert np.isfinite(final).all() and final[:, :3].mean() > 0, "bad image"
         result['image_mean'] = float(final[:, :3].mean() / (P * args.steps * (1 if tiles else world)))
         flops_per_sample = mesh_bytes = None
@@ -222,8 +253,8 @@ def main():
             oracle_renderer = r
             if args.scene == 'scene-mesh':
                 # the oracle walks the reference's octree stream: same tree, other serialisation
-                oracle_renderer = Renderer(load_scene('stream'), seed=args.seed, device=False)
-            base, flops_per_sample, mesh_bytes = cpu_baseline(oracle_renderer, tape, args.cpu_seconds)
+                oracle_renderer = Renderer(load_scene('stream'), seed=args.seed, device=False, rng_mode=args.rng)
+            base, flops_per_sample, mesh_bytes, counted = cpu_baseline(oracle_renderer, tape, args.cpu_seconds, n_timed)
             result['cpu_baseline'] = base
         avg_ms = float(np.mean(kernel_ms))
         launch_samples = float(r.n_pixels) * P
@@ -233,23 +264,28 @@ def main():
             achieved = mesh_bytes * launch_samples / (avg_ms * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'kernel': 'clr_render', 'unit': 'GB/s', 'peak': PEAK_HBM_GBS,
                     'achieved': achieved, 'frac': achieved / PEAK_HBM_GBS,
-                    'mesh_bytes_per_sample': mesh_bytes, 'flops_per_sample': flops_per_sample}
+                    'mesh_bytes_per_sample': mesh_bytes, 'flops_per_sample': flops_per_sample,
+                    'counted_over': counted}
         else:
             roof = {'bound': 'valu', 'kernel': 'clr_render', 'unit': 'TFLOP/s',
-                    'peak': PEAK_FP32_VECTOR_TFLOPS, 'peak_unpacked_fma': PEAK_FP32_SCALAR_FMA_TFLOPS}
+                    'peak': PEAK_FP32_VECTOR_TFLOPS, 'peak_non_fma_ops': PEAK_FP32_NON_FMA_TOPS}
             if flops_per_sample is not None:
                 achieved = flops_per_sample * launch_samples / (avg_ms * 1e-3) / 1e12
                 roof.update({'achieved': achieved, 'frac': achieved / PEAK_FP32_VECTOR_TFLOPS,
-                             'frac_unpacked_fma': achieved / PEAK_FP32_SCALAR_FMA_TFLOPS,
-                             'flops_per_sample': flops_per_sample})
+                             'frac_of_non_fma_ceiling': achieved / PEAK_FP32_NON_FMA_TOPS,
+                             'flops_per_sample': flops_per_sample, 'counted_over': counted})
         roof['kernel_ms_avg'] = avg_ms
         roof['traffic'] = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
-            # HBM bytes per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE of this same command
-            # (tools/profile.sh + tools/summarize_profile.py); keyed by scene and launch shape
-            key = '%s %dx%d p%d' % (args.scene, width, height, P)
-            roof['traffic'] = json.load(open(pmc)).get(key)
+            # HBM bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE passes over this same command
+            # (tools/profile.sh + tools/summarize_profile.py; counters cannot be read from inside the
+            # run), keyed by scene, launch shape and random number mode
+            key = '%s %dx%d p%d %s' % (args.scene, width, height, P, args.rng)
+            entry = json.load(open(pmc)).get(key)
+            if entry:
+                roof['traffic'] = entry['bytes_per_launch']
+                roof['traffic_source'] = entry['source']
         result['roofline'] = roof
         print(json.dumps(result))
     if use_dist:

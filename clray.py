@@ -6,7 +6,9 @@
 The scene file defines a module-level `scene`.  Renders `scene.samples_per_pixel` passes in
 batches (one kernel launch per batch), writes out.png and out.raw.npy (the float sum over all
 passes, also the `--append` resume format) at every refresh and prints rays/s.
-Extra flags: --size WxH, --spp N, --seed S, --device D, --batch B.
+Extra flags: --size WxH, --spp N, --seed S, --device D, --batch B, --rng, and
+--gpus N [--partition passes|tiles]: the render is shared by N GPUs of this node, one process per
+GPU under torch.distributed.run, with one RCCL exchange per refresh (raytracer_amd/multi_gpu.py).
 """
 import argparse
 import os
@@ -35,11 +37,23 @@ def main():
     ap.add_argument('--rng', choices=['tape', 'philox'], default='tape',
                     help="tape: the reference's random numbers, shared by all pixels of a pass; "
                          "philox: every pixel draws its own (less correlated noise)")
+    ap.add_argument('--gpus', type=int, default=1, help='GPUs of this node to share the render')
+    ap.add_argument('--partition', choices=['passes', 'tiles'], default='passes',
+                    help='passes: GPU g renders passes g, g+N, ... (one all-reduce per refresh); '
+                         'tiles: GPU g renders its slice of the frame (one all-gather per refresh)')
     ap.add_argument('scene')
     args = ap.parse_args()
 
-    startup_time = time.time()
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from raytracer_amd import multi_gpu
+    rank, local_rank, world = multi_gpu.worker_identity()
+    if args.gpus > 1 and world == 1:
+        # not yet a worker: start one process per GPU (before anything here touches a GPU) and leave
+        raise SystemExit(multi_gpu.launch_workers(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if world != max(args.gpus, 1):
+        raise SystemExit("--gpus %d, but started with WORLD_SIZE=%d" % (args.gpus, world))
+
+    startup_time = time.time()
     import raytracer_amd
     from raytracer_amd.imgutils import Image
     raytracer_amd.install_flat_aliases()          # `from objects import *` in reference scene files
@@ -51,10 +65,37 @@ def main():
         scene.samples_per_pixel = args.spp
 
     image = Image(RAW_OUTPUT_FILE if args.append else None, settings=scene.image)
-    renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device, rng_mode=args.rng)
+    n_rays = scene.image.size[0] * scene.image.size[1]
+    shard = multi_gpu.Shard(args.partition, rank, world, n_rays)
+    if world > 1:
+        if args.seed is None:
+            raise SystemExit("--gpus needs --seed: every GPU draws the same global sequence of passes")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        args.device = local_rank
+    renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device, rng_mode=args.rng,
+                                      **shard.renderer_arguments())
+    shard.configure(renderer)
     if scene.samples_per_pixel >= 64:
         renderer.tune_occupancy(passes=8)       # pays off for long renders only
     acc = renderer.acc
+    if world > 1:
+        # the accumulator lives in a torch tensor so that RCCL can combine the ranks' results
+        frame = torch.zeros((shard.frame_rows, 4), dtype=torch.float32, device='cuda')
+        renderer.use_image_buffer(shard.my_rows(frame)[:renderer.n_pixels].data_ptr())
+        combined = torch.empty_like(frame)
+
+    def whole_image():
+        """(H, W, 3) sums over all passes of all GPUs so far (every rank takes part, rank 0 uses it)."""
+        if world == 1:
+            return renderer.get_image()
+        combined.copy_(frame)
+        shard.combine(combined, dist)
+        from raytracer_amd.renderer import unpermute_rays
+        return unpermute_rays(combined[:n_rays, :3].cpu().numpy(), renderer.full_image_order,
+                              renderer.img_shape).astype(np.float64)
 
     total = scene.samples_per_pixel
     batch = args.batch or max(1, min(args.itr_per_refresh, 64))
@@ -62,29 +103,43 @@ def main():
     next_refresh = min(max(1, args.itr_per_refresh // 10), total)
     while done < total:
         n = min(batch, total - done, max(next_refresh - done, 1))
-        renderer.render_samples(done, n)
+        # passes [done, done + n) of the global sequence; with the passes partition this rank
+        # renders those whose index is rank modulo the number of GPUs
+        tape = renderer.make_tape(done, n)
+        mine = shard.local_tape(tape) if shard.pass_stride == 1 else tuple(
+            x[(shard.pass_offset - done) % world::world] if x is not None else None for x in tape)
+        if mine[0].shape[0]:
+            renderer.render_tape(mine, first_pass=done + (shard.pass_offset - done) % shard.pass_stride)
         done += n
         elapsed = time.time() - startup_time
         per_second = done / elapsed
-        print('%d/%d, depth: %d, %d rays/s elapsed: %.2f s, eta: %.1f min' % (
-            done, total, scene.max_bounces - 1, int(renderer.rays_per_sample() * per_second),
-            elapsed, (total - done) / per_second / 60.0))
+        if rank == 0:
+            print('%d/%d, depth: %d, %d rays/s elapsed: %.2f s, eta: %.1f min' % (
+                done, total, scene.max_bounces - 1, int(n_rays * per_second),
+                elapsed, (total - done) / per_second / 60.0))
         if done >= next_refresh or done == total:
-            imgdata = renderer.get_image()
+            imgdata = whole_image()
+            step = args.itr_per_refresh if done >= args.itr_per_refresh else max(1, args.itr_per_refresh // 10)
+            next_refresh = min(done + step, total)
+            if rank != 0:
+                continue
             print('image mean:', np.mean(np.ravel(imgdata)))
             if not args.no_window:
                 image.show(imgdata)
             image.save_raw(RAW_OUTPUT_FILE, imgdata)
             try:
+                if world > 1:
+                    raise NotImplementedError       # the device tone mapper reads one GPU's accumulator
                 # 8-bit image straight from the device accumulator (tonemap.py)
                 from PIL import Image as PilImage
                 PilImage.fromarray(renderer.get_display_image(scene.image, base=image.data), 'RGB').save(PNG_OUTPUT_FILE)
             except NotImplementedError:
-                image.save_png(PNG_OUTPUT_FILE, imgdata)        # flares etc.: host pipeline
+                image.save_png(PNG_OUTPUT_FILE, imgdata)        # flares, several GPUs: host pipeline
             acc.output_profiling_info()
-            step = args.itr_per_refresh if done >= args.itr_per_refresh else max(1, args.itr_per_refresh // 10)
-            next_refresh = min(done + step, total)
-    acc.output_profiling_info()
+    if rank == 0:
+        acc.output_profiling_info()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -69,6 +69,18 @@ int clr_program_load(clr_ctx *ctx, const void *binary, size_t size, clr_program 
 /* Version of the hiprtc that this process compiles with (part of a cache key). */
 int clr_compiler_version(int *major, int *minor);
 
+/* Resources of one kernel of a loaded program, as the code object states them (the reference
+ * prints per-kernel statistics only, accelerator.py:155-166; this is what an occupancy choice
+ * needs): registers per lane, bytes of scratch ("private segment", register spills and stack)
+ * per lane, static LDS bytes per block. */
+typedef struct clr_kernel_info_t {
+    int vgprs;
+    int scratch_bytes;
+    int lds_bytes;
+    int max_threads_per_block;
+} clr_kernel_info_t;
+int clr_kernel_info(clr_program *prog, const char *kernel, clr_kernel_info_t *out);
+
 /* ---- buffers: replace to_device / new_array / new_const_buffer / enqueue_copy / Array.fill /
  * Array.get (accelerator.py:91-153, renderer.py:306-311) */
 int clr_buffer_alloc(clr_ctx *ctx, size_t bytes, void **device_ptr);
@@ -82,6 +94,14 @@ int clr_buffer_fill32(clr_ctx *ctx, void *device_ptr, uint32_t value, size_t cou
  * bracketed by HIP events on `stream` and the call waits for it. */
 int clr_launch(clr_program *prog, const char *kernel, const unsigned grid[3],
                const unsigned block[3], int n_args, void **args, void *stream, float *elapsed_ms);
+
+/* ---- timing a region of launches on a stream with one HIP event pair: the per-kernel device
+ * times of Accelerator.call / output_profiling_info (accelerator.py:83-89, 155-166) for launches
+ * that go out back to back without a host wait in between.  clr_timer_end records the end and
+ * returns at once; clr_timer_elapsed waits for it. */
+int clr_timer_begin(clr_ctx *ctx, void *stream);
+int clr_timer_end(clr_ctx *ctx, void *stream);
+int clr_timer_elapsed(clr_ctx *ctx, float *elapsed_ms);
 
 /* ---- the hot path: replaces the whole of Renderer.render_sample + compute_next_path_segment
  * (renderer.py:293-433) for `n_passes` consecutive sample passes. */
@@ -115,6 +135,10 @@ typedef struct clr_render_args {
      * non-NULL pass_log are required for such a program and must be 0 / NULL for any other. */
     void *pass_log;
     int pass_groups;
+    /* per-pixel random numbers when the passes are striped over several GPUs: local pass j of
+     * this call has the global index first_pass + j * pass_stride (0 is read as 1), so that every
+     * GPU draws exactly the numbers a single GPU would draw for the same pass */
+    int pass_stride;
 } clr_render_args;
 
 int clr_render_passes(clr_program *prog, const clr_render_args *args, void *stream,

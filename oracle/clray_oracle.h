@@ -74,6 +74,7 @@ typedef struct orc_rng {
     int first_ray;                      /* global ray index of pixel 0 (tile partitioning) */
     int n_lights;
     const float *lights;                /* per light 8 floats: centre xyz, R, area, min distance, id (int bits), 0 */
+    int pass_stride;                    /* global index of local pass j = first_pass + j * pass_stride; 0 = 1 */
 } orc_rng;
 
 #define ORC_PASS_RECORD 6

@@ -66,7 +66,7 @@ _libs = {}
 class Rng(ctypes.Structure):
     _fields_ = [('seed_lo', ctypes.c_uint), ('seed_hi', ctypes.c_uint), ('first_pass', ctypes.c_int),
                 ('first_ray', ctypes.c_int), ('n_lights', ctypes.c_int),
-                ('lights', ctypes.POINTER(ctypes.c_float))]
+                ('lights', ctypes.POINTER(ctypes.c_float)), ('pass_stride', ctypes.c_int)]
 
 
 def load(count_flops=False):
@@ -302,17 +302,25 @@ class OracleScene:
             o.normal = ctypes.cast(getattr(lib, 'orc_gen_normal_%d' % n), ctypes.c_void_p).value
 
     # ---- runs
-    def render(self, tape, img=None, debug=False, n_threads=0, count_flops=False, first_pass=0):
+    def render(self, tape, img=None, debug=False, n_threads=0, count_flops=False, first_pass=0, pixels=None):
         """Add the passes of `tape` to img (n_pixels x 4 float32).  Returns (img, dump, flops).
         With a renderer in per-pixel random number mode the bounce part of the tape is None and
-        `first_pass` is the global index of the tape's first pass."""
+        `first_pass` is the global index of the tape's first pass.
+        pixels: ray indices to walk instead of the whole frame (tape mode only: there every pixel's
+        path depends on its camera ray and the shared tape alone); img then has one row per index."""
         r = self.renderer
         passes, bounces, rows = tape
+        if pixels is not None:
+            assert getattr(r, 'rng_mode', 'tape') == 'tape' and not debug
+            cam = np.ascontiguousarray(r.host_cam[pixels], np.float32)
+            full = self.renderer
+            r = type('Subset', (), dict(host_cam=cam, n_pixels=cam.shape[0], scene=full.scene, rng_mode='tape'))()
         rng = None
         if getattr(r, 'rng_mode', 'tape') == 'philox':
             lights = np.ascontiguousarray(r.light_table, np.float32)
             rng = Rng(r.rng_seed & 0xffffffff, (r.rng_seed >> 32) & 0xffffffff, int(first_pass),
-                      r.ray_range[0] if r.ray_range else 0, r.n_lights, _fptr(lights))
+                      r.ray_range[0] if r.ray_range else 0, r.n_lights, _fptr(lights),
+                      int(getattr(r, 'pass_stride', 1)))
             bounces = np.zeros(1, np.float32)
         n = passes.shape[0]
         if img is None:

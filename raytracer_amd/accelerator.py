@@ -36,11 +36,17 @@ class RenderArgs(ctypes.Structure):
                 ('debug_dump', ctypes.c_void_p), ('per_pixel_rng', ctypes.c_int),
                 ('rng_seed_lo', ctypes.c_uint), ('rng_seed_hi', ctypes.c_uint),
                 ('first_pass', ctypes.c_int), ('first_ray', ctypes.c_int),
-                ('pass_log', ctypes.c_void_p), ('pass_groups', ctypes.c_int)]
+                ('pass_log', ctypes.c_void_p), ('pass_groups', ctypes.c_int),
+                ('pass_stride', ctypes.c_int)]
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.struct_size = ctypes.sizeof(RenderArgs)
+
+
+class KernelInfo(ctypes.Structure):
+    _fields_ = [('vgprs', ctypes.c_int), ('scratch_bytes', ctypes.c_int), ('lds_bytes', ctypes.c_int),
+                ('max_threads_per_block', ctypes.c_int)]
 
 
 class OctreeInfo(ctypes.Structure):
@@ -70,6 +76,9 @@ def load_library():
         'clr_ctx_destroy': (ci, [vp]),
         'clr_device_info': (ci, [vp, P(DeviceInfo)]),
         'clr_sync': (ci, [vp, vp]),
+        'clr_timer_begin': (ci, [vp, vp]),
+        'clr_timer_end': (ci, [vp, vp]),
+        'clr_timer_elapsed': (ci, [vp, P(ctypes.c_float)]),
         'clr_program_build': (ci, [vp, cp, ci, P(cp), P(vp)]),
         'clr_program_destroy': (ci, [vp]),
         'clr_program_set_global': (ci, [vp, cp, vp, ctypes.c_size_t]),
@@ -78,6 +87,7 @@ def load_library():
         'clr_binary_free': (None, [vp]),
         'clr_program_load': (ci, [vp, vp, ctypes.c_size_t, P(vp)]),
         'clr_compiler_version': (ci, [P(ci), P(ci)]),
+        'clr_kernel_info': (ci, [vp, cp, P(KernelInfo)]),
         'clr_buffer_alloc': (ci, [vp, ctypes.c_size_t, P(vp)]),
         'clr_buffer_free': (ci, [vp, vp]),
         'clr_buffer_upload': (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
@@ -277,6 +287,20 @@ class Accelerator:
     def finish(self, stream=None):
         _check(self.lib.clr_sync(self.ctx, stream))
 
+    def timer_begin(self, stream=None):
+        """Start of a timed region of launches on `stream` (one HIP event pair around all of them)."""
+        _check(self.lib.clr_timer_begin(self.ctx, stream))
+
+    def timer_end(self, stream=None, wait=True):
+        """End of the region: milliseconds, or with wait=False a function that waits and returns them."""
+        _check(self.lib.clr_timer_end(self.ctx, stream))
+
+        def elapsed():
+            ms = ctypes.c_float(0)
+            _check(self.lib.clr_timer_elapsed(self.ctx, ctypes.byref(ms)))
+            return ms.value
+        return elapsed() if wait else elapsed
+
     # ---- program
     def build_program(self, prog_code, options=(), keep_previous=False):
         """Compile and load `prog_code` and make it the current program.  keep_previous leaves
@@ -302,6 +326,12 @@ class Accelerator:
     def drop_program(self, prog):
         if prog is not None and prog is not self.prog:
             self.lib.clr_program_destroy(prog)
+
+    def kernel_info(self, kernel='clr_render', prog=None):
+        """Registers, scratch bytes per lane and LDS bytes of a kernel of the program."""
+        info = KernelInfo()
+        _check(self.lib.clr_kernel_info(prog if prog is not None else self.prog, kernel.encode(), ctypes.byref(info)))
+        return {f: getattr(info, f) for f, _ in KernelInfo._fields_}
 
     def set_global(self, name, host):
         host = np.ascontiguousarray(host)

@@ -7,6 +7,9 @@ import os
 import sys
 
 
+COMPILE_ERROR = 3        # exit status: the compiler ran and refused the source (stderr = its log)
+
+
 def main(argv):
     arch = argv[1]
     options = [o.encode() for o in argv[2:]]
@@ -20,7 +23,7 @@ def main(argv):
     binary, size = ctypes.c_void_p(), ctypes.c_size_t(0)
     if lib.clr_compile(source, len(options), arr, arch.encode(), ctypes.byref(binary), ctypes.byref(size)):
         sys.stderr.write(lib.clr_last_error().decode('utf-8', 'replace'))
-        return 1
+        return COMPILE_ERROR
     sys.stdout.buffer.write(ctypes.string_at(binary, size.value))
     sys.stdout.buffer.flush()
     lib.clr_binary_free(binary)

@@ -56,7 +56,8 @@ int resolve_scratch(int device) {
 
 struct clr_ctx {
     int device;
-    hipEvent_t ev_start, ev_stop;
+    hipEvent_t ev_start, ev_stop;         // around one timed launch
+    hipEvent_t timer_start, timer_stop;   // clr_timer_begin / clr_timer_end
 };
 
 struct clr_program {
@@ -137,6 +138,8 @@ int clr_ctx_create(int device_index, clr_ctx **out) {
     ctx->device = device_index;
     if (int rc = check(hipEventCreate(&ctx->ev_start), "hipEventCreate")) { delete ctx; return rc; }
     if (int rc = check(hipEventCreate(&ctx->ev_stop), "hipEventCreate")) { delete ctx; return rc; }
+    if (int rc = check(hipEventCreate(&ctx->timer_start), "hipEventCreate")) { delete ctx; return rc; }
+    if (int rc = check(hipEventCreate(&ctx->timer_stop), "hipEventCreate")) { delete ctx; return rc; }
     *out = ctx;
     return 0;
 }
@@ -146,6 +149,8 @@ int clr_ctx_destroy(clr_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
+    (void)hipEventDestroy(ctx->timer_start);
+    (void)hipEventDestroy(ctx->timer_stop);
     delete ctx;
     return 0;
 }
@@ -169,6 +174,26 @@ int clr_device_info(clr_ctx *ctx, clr_device_info_t *out) {
 int clr_sync(clr_ctx *ctx, void *stream) {
     if (int rc = set_device(ctx)) return rc;
     CLR_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int clr_timer_begin(clr_ctx *ctx, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    CLR_TRY(hipEventRecord(ctx->timer_start, (hipStream_t)stream));
+    return 0;
+}
+
+int clr_timer_end(clr_ctx *ctx, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    CLR_TRY(hipEventRecord(ctx->timer_stop, (hipStream_t)stream));
+    return 0;
+}
+
+int clr_timer_elapsed(clr_ctx *ctx, float *elapsed_ms) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!elapsed_ms) return fail("null output pointer");
+    CLR_TRY(hipEventSynchronize(ctx->timer_stop));
+    CLR_TRY(hipEventElapsedTime(elapsed_ms, ctx->timer_start, ctx->timer_stop));
     return 0;
 }
 
@@ -278,6 +303,19 @@ int clr_program_set_global(clr_program *prog, const char *name, const void *host
     return 0;
 }
 
+int clr_kernel_info(clr_program *prog, const char *kernel, clr_kernel_info_t *out) {
+    if (!prog || !kernel || !out) return fail("null argument");
+    if (int rc = set_device(prog->ctx)) return rc;
+    hipFunction_t fn;
+    CLR_TRY(hipModuleGetFunction(&fn, prog->module, kernel));
+    memset(out, 0, sizeof(*out));
+    CLR_TRY(hipFuncGetAttribute(&out->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn));
+    CLR_TRY(hipFuncGetAttribute(&out->scratch_bytes, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn));
+    CLR_TRY(hipFuncGetAttribute(&out->lds_bytes, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn));
+    CLR_TRY(hipFuncGetAttribute(&out->max_threads_per_block, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, fn));
+    return 0;
+}
+
 int clr_buffer_alloc(clr_ctx *ctx, size_t bytes, void **device_ptr) {
     if (int rc = set_device(ctx)) return rc;
     if (!device_ptr) return fail("null output pointer");
@@ -339,6 +377,7 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
         return fail("clr_render_passes: per_pixel_rng does not match the random number mode the program was generated for");
     if (!prog->rng_mode && !a->bounce_tape)
         return fail("clr_render_passes: bounce_tape is required for a tape program");
+    if (a->pass_stride < 0) return fail("clr_render_passes: pass_stride must not be negative");
     if (a->debug_dump && a->n_passes != 1)
         return fail("clr_render_passes: debug_dump needs n_passes == 1");
     if (static_log) {
@@ -373,8 +412,9 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     // before clr_reduce_log reads it, so what an earlier call left in the static array is never seen
     void *pass_log = static_log ? static_log : a->pass_log;
     int pass_groups = a->pass_groups;
+    int pass_stride = a->pass_stride > 0 ? a->pass_stride : 1;
     void *args[] = {&img, &cam, &pt, &bt, &mr, &vd, &id, &n_pixels, &n_passes, &regen, &dbg,
-                    &seed_lo, &seed_hi, &first_pass, &first_ray, &pass_log, &pass_groups};
+                    &seed_lo, &seed_hi, &first_pass, &first_ray, &pass_log, &pass_groups, &pass_stride};
     const unsigned block[3] = {kBlock, 1, 1};
     if (!prog->split_mode) {
         const unsigned grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -51,9 +52,10 @@ struct Lines {
 bool load(const char *path, Lines &in) {
     FILE *f = fopen(path, "rb");
     if (!f) return false;
-    fseek(f, 0, SEEK_END);
+    // a regular, seekable file: a FIFO or a /proc entry reports no size (-1)
+    if (fseek(f, 0, SEEK_END) != 0) { fclose(f); return false; }
     long size = ftell(f);
-    fseek(f, 0, SEEK_SET);
+    if (size < 0 || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return false; }
     in.text.resize((size_t)size + 1);
     size_t got = size ? fread(in.text.data(), 1, (size_t)size, f) : 0;
     fclose(f);
@@ -132,6 +134,9 @@ int read_off(Lines &in, clr_mesh &mesh) {
     }
     if (!parse_ints(p, counts) || counts.size() != 3 || counts[0] < 0 || counts[1] < 0)
         return fail("OFF: expected `n_points n_faces n_edges`" + where(in));
+    // every record takes a line of at least two bytes: counts beyond that are not this file's
+    if ((size_t)counts[0] > in.text.size() / 2 || (size_t)counts[1] > in.text.size() / 2)
+        return fail("OFF: the header announces more records than the file can hold" + where(in));
     std::vector<double> row;
     mesh.vertices.reserve((size_t)counts[0] * 3);
     for (long v = 0; v < counts[0]; ++v) {
@@ -159,6 +164,8 @@ int read_zipper(Lines &in, clr_mesh &mesh) {
         }
     }
     if (n_vertices < 0 || n_faces < 0) return fail("zipper: header lacks element vertex / element face");
+    if ((size_t)n_vertices > in.text.size() / 2 || (size_t)n_faces > in.text.size() / 2)
+        return fail("zipper: the header announces more records than the file can hold");
     std::vector<double> row;
     mesh.vertices.reserve((size_t)n_vertices * 3);
     for (long v = 0; v < n_vertices; ++v) {
@@ -191,11 +198,20 @@ extern "C" {
 
 int clr_mesh_read(const char *path, int format, clr_mesh **out) {
     if (!path || !out) return fail("null argument");
-    Lines in;
-    if (!load(path, in)) return fail(std::string("cannot open ") + path);
-    clr_mesh *mesh = new clr_mesh;
-    int rc = format == 0 ? read_off(in, *mesh) : format == 1 ? read_zipper(in, *mesh) : fail("unknown mesh format");
-    if (rc) { delete mesh; return rc; }
+    clr_mesh *mesh = nullptr;
+    try {                                  // no C++ exception may cross the C boundary
+        Lines in;
+        if (!load(path, in)) return fail(std::string("cannot read ") + path + " (missing, or not a regular file)");
+        mesh = new clr_mesh;
+        int rc = format == 0 ? read_off(in, *mesh) : format == 1 ? read_zipper(in, *mesh) : fail("unknown mesh format");
+        if (rc) { delete mesh; return rc; }
+    } catch (const std::exception &e) {
+        delete mesh;
+        return fail(std::string("clr_mesh_read: ") + e.what());
+    } catch (...) {
+        delete mesh;
+        return fail("clr_mesh_read: unknown failure");
+    }
     *out = mesh;
     return 0;
 }
@@ -221,6 +237,7 @@ int clr_mesh_destroy(clr_mesh *mesh) {
 
 int clr_mesh_unique_faces(const int *faces, int n_faces, int *kept, int *n_kept) {
     if (!faces || !kept || !n_kept || n_faces < 0) return fail("bad arguments");
+    try {
     std::unordered_set<std::array<int, 3>, KeyHash> seen;
     seen.reserve((size_t)n_faces * 2);
     int count = 0;
@@ -233,6 +250,9 @@ int clr_mesh_unique_faces(const int *faces, int n_faces, int *kept, int *n_kept)
         if (seen.insert(k).second) kept[count++] = f;
     }
     *n_kept = count;
+    } catch (const std::exception &e) {
+        return fail(std::string("clr_mesh_unique_faces: ") + e.what());
+    }
     return 0;
 }
 

@@ -315,7 +315,7 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
            const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
            const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg,
            const uint rng_seed_lo, const uint rng_seed_hi, const int first_pass, const int first_ray,
-           float * __restrict__ pass_log, const int pass_groups)
+           float * __restrict__ pass_log, const int pass_groups, const int pass_stride)
 {
 ### if renderer.split_passes
     // pass-split mode: lane (k, group) walks the passes [group * per_group, ...) of pixel k and
@@ -388,7 +388,7 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
             // the light sample feeds the visibility test and the diffuse stage, both of which
             // need a diffuse bounce to be left and are skipped on the last segment
             const BounceSample B = clr_draw_bounce(rng_seed_lo, rng_seed_hi, (uint)(first_ray + k),
-                                                   (uint)(first_pass + pass), (uint)segment,
+                                                   (uint)(first_pass + pass * pass_stride), (uint)segment,
                                                    !is_last && s.diffusions_left > 0);
 ### else
             const BounceSample B = clr_load_bounce(bounce_tape + ((size_t)pass * CLR_MAX_BOUNCES + segment) * CLR_BOUNCE_STRIDE);

@@ -77,13 +77,22 @@ def compile_here(source, options, arch):
         lib.clr_binary_free(binary)
 
 
+class ChildUnavailable(OSError):
+    """The compile child could not do its job for a reason other than the source text."""
+
+
 def compile_in_child(source, options, arch):
-    """Compile with the system's hiprtc in a child process that never touches the GPU."""
+    """Compile with the system's hiprtc in a child process that never touches the GPU.  Raises
+    ClrError with the compiler's log if the source does not compile, ChildUnavailable (an OSError)
+    if the child could not run."""
+    from .compile_worker import COMPILE_ERROR
     proc = subprocess.run([sys.executable, os.path.join(_HERE, 'compile_worker.py'), arch] + list(options),
                           input=source.encode('ascii'), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if proc.returncode == COMPILE_ERROR:
+        raise accelerator.ClrError(proc.stderr.decode('utf-8', 'replace'))
     if proc.returncode != 0 or not proc.stdout:
-        raise accelerator.ClrError(proc.stderr.decode('utf-8', 'replace') or
-                                   'compile_worker failed with exit status %d' % proc.returncode)
+        raise ChildUnavailable('compile_worker failed with exit status %d: %s'
+                               % (proc.returncode, proc.stderr.decode('utf-8', 'replace')[-500:]))
     return proc.stdout
 
 
@@ -119,10 +128,12 @@ def get_binary(source, options, arch):
     if use_child:
         try:
             binary, how = compile_in_child(source, options, arch), 'child'
-        except (OSError, accelerator.ClrError):
-            # no child processes here (some profilers and sandboxes refuse them), or the source
-            # does not compile: compile with what this process has, which reports the latter
+        except OSError:
+            # no child processes here (some profilers and sandboxes refuse them): compile with the
+            # hiprtc this process has mapped - another compiler than the key above names, so the
+            # result is not kept.  (A source that does not compile raises ClrError with the log.)
             binary, how = compile_here(source, options, arch), 'here'
+            path = None
     else:
         binary, how = compile_here(source, options, arch), 'here'
     if path:

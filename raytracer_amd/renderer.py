@@ -11,6 +11,7 @@ the same order, stored in a tape and replayed by the device.
 """
 import itertools
 import math
+import os
 import numpy as np
 
 from . import geometry as camera
@@ -39,6 +40,35 @@ def pass_groups_for(n_pixels, n_passes, at_least=1):
     return -(-n_passes // per_group)
 
 
+def unpermute_rays(per_ray, image_order, img_shape):
+    """(n, C) values in ray order -> (H, W, C) image; image_order maps ray -> (row, col)."""
+    out = np.zeros(tuple(img_shape) + per_ray.shape[1:], dtype=per_ray.dtype)
+    out[image_order[:, 0], image_order[:, 1]] = per_ray
+    return out
+
+
+LOG_BYTES_LIMIT = 1 << 33       # addend log of a pass-split launch: 8 GB at most
+
+
+def log_passes_limit(n_pixels, max_bounces, limit=LOG_BYTES_LIMIT):
+    """Passes whose addend log (1 + 6 max_bounces floats per pass and pixel) fits in `limit` bytes."""
+    return max(1, limit // ((1 + 6 * max_bounces) * n_pixels * 4))
+
+
+SPILL_MARGIN = 0.03
+
+
+def pick_occupancy_hint(timings, scratch):
+    """The fastest candidate among those with the least scratch per lane, unless one that spills
+    more beats it by more than SPILL_MARGIN."""
+    least = min(scratch.values())
+    lean = min((h for h in timings if scratch[h] == least), key=timings.get)
+    best = min(timings, key=timings.get)
+    if scratch[best] > least and timings[best] > (1.0 - SPILL_MARGIN) * timings[lean]:
+        return lean
+    return best
+
+
 class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
@@ -56,7 +86,13 @@ class Renderer:
         if rng_mode not in ('tape', 'philox'):
             raise ValueError("rng_mode must be 'tape' or 'philox'")
         self.rng_mode = rng_mode
-        self.rng_seed = (0 if seed is None else int(seed)) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 & (2**64 - 1)
+        # passes striped over several GPUs (multi_gpu.py): local pass j has the global index
+        # first_pass + j * pass_stride in the per-pixel random number counter
+        self.pass_stride = 1
+        # unseeded (like the reference's global numpy generator): a fresh key per process, so that
+        # `clray.py --append` runs add independent samples
+        key = int.from_bytes(os.urandom(8), 'little') if seed is None else int(seed)
+        self.rng_seed = key * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 & (2**64 - 1)
 
         self._group_objects()
         self._init_lights()
@@ -239,7 +275,7 @@ class Renderer:
         self.pixel_angle = fovx_rad / scene.image.size[0]
         self.img_shape = tuple(scene.image.size[::-1])          # (H, W)
         self.n_pixels = self.img_shape[0] * self.img_shape[1]
-        self.image_order = self.get_image_order()
+        self.image_order = self.full_image_order = self.get_image_order()
         if self.ray_range is not None:
             first, count = self.ray_range
             assert 0 <= first and first + count <= self.n_pixels and count > 0
@@ -403,9 +439,14 @@ class Renderer:
                 self.acc.use_program(built[hint][0])
                 samples[hint].append(self.render_tape(tape)[0])
         timings = {hint: float(np.median(v)) for hint, v in samples.items()}
+        # scratch bytes per lane of each build: a build that needs more than the leanest one
+        # spills registers (inside the segment loop, as measured on scene-dev with hint 7: 7 x the
+        # algorithmic HBM writes), which hurts any neighbour on the GPU and is bought by noise-level
+        # gains; such a build has to win by SPILL_MARGIN to be chosen
+        scratch = {hint: self.acc.kernel_info('clr_render', prog=built[hint][0])['scratch_bytes'] for hint in candidates}
         if verbose:
-            print('occupancy hints, median ms:', timings)
-        best = min(timings, key=timings.get)
+            print('occupancy hints, median ms:', timings, 'scratch bytes per lane:', scratch)
+        best = pick_occupancy_hint(timings, scratch)
         self.min_waves_per_simd = best
         self.prog, self.program_code = built[best]
         self.acc.use_program(self.prog)
@@ -415,6 +456,7 @@ class Renderer:
         self.img = saved_img
         self.dev_pass_tape, self.dev_bounce_tape, self.dev_rows, self._tape_capacity, self._resident_passes = saved_tape
         self.occupancy_timings = timings
+        self.occupancy_scratch = scratch
         return best
 
     def _upload_tape(self, tape):
@@ -453,8 +495,8 @@ class Renderer:
         (pass-split programs; the caller keeps `count` within the library's static log)."""
         assert 0 <= first and first + count <= self._resident_passes
         if self.split_passes and not static_log:
-            # keep the addend log below 8 GB: longer ranges go as several launches
-            most = max(1, (1 << 33) // ((1 + 6 * self.scene.max_bounces) * self.n_pixels * 4))
+            # keep the addend log below LOG_BYTES_LIMIT: longer ranges go as several launches
+            most = self.max_passes_per_launch()
             if count > most:
                 ms = [self.render_resident(f, min(most, first + count - f), stream, timed)
                       for f in range(first, first + count, most)]
@@ -468,8 +510,15 @@ class Renderer:
             vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
             n_pixels=self.n_pixels, n_passes=count, regenerate=int(self.regenerate),
             debug_dump=None, **self._split_args(count, static_log=static_log),
-            **self._rng_args(self._resident_first_pass + first))
+            **self._rng_args(self._resident_first_pass + first * self.pass_stride))
         return self.acc.render_passes(args, stream=stream, timed=timed, static_log=static_log)
+
+    def max_passes_per_launch(self):
+        """Passes one launch of a pass-split program may cover so that its addend log stays below
+        LOG_BYTES_LIMIT (None for a one-lane-per-pixel program: no log, no limit)."""
+        if not self.split_passes:
+            return None
+        return log_passes_limit(self.n_pixels, self.scene.max_bounces)
 
     def _split_args(self, n_passes, debug=False, static_log=False):
         """The pass-split fields of clr_render_args (empty for a one-lane-per-pixel program)."""
@@ -488,12 +537,23 @@ class Renderer:
         """The per-pixel random number fields of clr_render_args."""
         return dict(per_pixel_rng=int(self.rng_mode == 'philox'),
                     rng_seed_lo=self.rng_seed & 0xffffffff, rng_seed_hi=(self.rng_seed >> 32) & 0xffffffff,
-                    first_pass=int(first_pass), first_ray=self.ray_range[0] if self.ray_range else 0)
+                    first_pass=int(first_pass), first_ray=self.ray_range[0] if self.ray_range else 0,
+                    pass_stride=int(self.pass_stride))
 
     def render_tape(self, tape, debug=False, stream=None, timed=True, first_pass=0, static_log=False):
         """Render the passes described by `tape` and add them to the image accumulator.
         Returns (kernel milliseconds, debug dump or None)."""
         n = tape[0].shape[0]
+        most = self.max_passes_per_launch()
+        if most is not None and n > most and not debug and not static_log:
+            # the CLI's batches of 64 passes would need a 13 GB log at 1080p: several launches
+            total = 0.0
+            for f in range(0, n, most):
+                part = tuple(x[f:f + most] if x is not None else None for x in tape)
+                ms, _ = self.render_tape(part, stream=stream, timed=timed,
+                                         first_pass=first_pass + f * self.pass_stride)
+                total += ms
+            return total, None
         self._upload_tape(tape)
         dump = None
         if debug:
@@ -540,9 +600,7 @@ class Renderer:
     # ------------------------------------------------------------------ results
     def unpermute(self, per_ray):
         """(n_pixels, C) in ray order -> (H, W, C) image."""
-        out = np.zeros(self.img_shape + per_ray.shape[1:], dtype=per_ray.dtype)
-        out[self.image_order[:, 0], self.image_order[:, 1]] = per_ray
-        return out
+        return unpermute_rays(per_ray, self.image_order, self.img_shape)
 
     def get_image(self):
         """Sum over all passes so far, (H, W, 3) (reference renderer.py:24-28)."""

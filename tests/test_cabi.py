@@ -32,10 +32,11 @@ def test_python_prototypes_cover_the_header():
 
 def test_struct_layout_matches_header():
     # size word, 7 pointers, 3 ints, padding, pointer, 5 ints of the per-pixel random number mode +
-    # padding, then the pass-split pair: pointer, int + padding
+    # padding, then the pass-split pair: pointer, int, and the pass stride
     assert ctypes.sizeof(accelerator.RenderArgs) == 8 + 7 * 8 + 3 * 4 + 4 + 8 + 5 * 4 + 4 + 8 + 4 + 4
     assert accelerator.RenderArgs.struct_size.offset == 0 and accelerator.RenderArgs.img.offset == 8
     assert accelerator.RenderArgs.pass_log.offset == 112 and accelerator.RenderArgs.pass_groups.offset == 120
+    assert accelerator.RenderArgs.pass_stride.offset == 124
     assert accelerator.RenderArgs.debug_dump.offset == 80
     assert accelerator.RenderArgs.per_pixel_rng.offset == 88 and accelerator.RenderArgs.first_ray.offset == 104
     assert accelerator.RenderArgs().struct_size == ctypes.sizeof(accelerator.RenderArgs)

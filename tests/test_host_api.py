@@ -306,3 +306,43 @@ def test_pass_split_policy():
     assert pass_groups_for(320 * 240, 30) == 15                   # 21 lanes wanted, 2 passes per group: 15 groups
     for size, split in (((320, 240), True), ((800, 600), True), ((1024, 768), False), ((1920, 1080), False)):
         assert Renderer(load_scene('scene-dev', size), device=False, seed=0).split_passes is split
+
+
+def test_occupancy_choice_avoids_builds_that_spill_for_noise_level_gains():
+    from raytracer_amd.renderer import pick_occupancy_hint
+    # hint 7 is 0.4 % faster but needs scratch that the others do not: not worth it
+    timings = {None: 1.40, 4: 1.38, 5: 1.30, 6: 1.249, 7: 1.244, 8: 1.9}
+    scratch = {None: 64, 4: 64, 5: 64, 6: 64, 7: 264, 8: 900}
+    assert pick_occupancy_hint(timings, scratch) == 6
+    # a build that spills but wins clearly is taken
+    timings[7] = 1.10
+    assert pick_occupancy_hint(timings, scratch) == 7
+    # no difference in scratch: plain minimum
+    assert pick_occupancy_hint({None: 2.0, 5: 1.5}, {None: 0, 5: 0}) == 5
+
+
+def test_pass_split_launches_are_cut_to_bound_the_addend_log():
+    from raytracer_amd.renderer import Renderer, log_passes_limit, LOG_BYTES_LIMIT
+    # 1080p, max_bounces 4: 25 floats per pass and pixel = 207 MB per pass -> 41 passes in 8 GB
+    assert log_passes_limit(1920 * 1080, 4) == LOG_BYTES_LIMIT // (25 * 1920 * 1080 * 4) == 41
+    assert log_passes_limit(3840 * 2160, 5) == 8
+    assert log_passes_limit(10 ** 9, 5) == 1                       # never less than one pass
+    scene = load_scene('scene-dev', (64, 48))
+    r = Renderer(scene, device=False, seed=0, split_passes=True)
+    assert r.max_passes_per_launch() == log_passes_limit(64 * 48, scene.max_bounces)
+    assert Renderer(load_scene('scene-dev', (64, 48)), device=False, seed=0, split_passes=False).max_passes_per_launch() is None
+    # render_tape cuts a long tape into launches of at most that many passes, numbered globally
+    calls = []
+    r.max_passes_per_launch = lambda: 3
+    r._upload_tape = lambda tape: None
+    r.dev_pass_tape = r.dev_bounce_tape = r.cam = r.img = r.dev_vector_data = r.dev_integer_data = type('B', (), {'ptr': 0})()
+    r.dev_rows = None
+    r._split_args = lambda n, debug=False, static_log=False: {}
+
+    class Acc:
+        def render_passes(self, args, stream=None, timed=True, static_log=False):
+            calls.append((args.n_passes, args.first_pass))
+            return 1.0
+    r.acc = Acc()
+    ms, _ = r.render_tape(r.make_tape(0, 8), first_pass=10)
+    assert calls == [(3, 10), (3, 13), (2, 16)] and ms == 3.0

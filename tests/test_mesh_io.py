@@ -2,6 +2,7 @@
 reference's mesh_formats.py, on generated files: bit-exact vertices, identical triangles,
 same rejections."""
 import io
+import os
 import time
 
 import numpy as np
@@ -99,3 +100,30 @@ def test_round_trip_of_a_generated_mesh_and_speed(tmp_path):
     python = time.time() - t0
     assert np.array_equal(np.array(pv), nv) and np.array_equal(np.array(pt, dtype=np.int32), nt)
     assert native < python
+
+
+def test_hostile_headers_and_unseekable_files_fail_cleanly(tmp_path):
+    """Counts a file cannot hold and files without a size are refused with an error, not with an
+    allocation failure crossing the C boundary (which would end the Python process)."""
+    big = tmp_path / 'big.off'
+    big.write_text('OFF\n2000000000 5 0\n0 0 0\n')
+    with pytest.raises(ClrError) as err:
+        read_mesh(str(big))
+    assert 'more records than the file can hold' in str(err.value)
+    bigply = tmp_path / 'big.ply'
+    bigply.write_text('ply\nelement vertex 3\nelement face 1999999999\nend_header\n0 0 0\n')
+    with pytest.raises(ClrError):
+        read_mesh(str(bigply))
+    fifo = str(tmp_path / 'pipe.off')
+    os.mkfifo(fifo)
+    import threading
+
+    def writer():
+        with open(fifo, 'w') as f:
+            f.write('OFF\n1 0 0\n0 0 0\n')
+    t = threading.Thread(target=writer)
+    t.start()
+    with pytest.raises(ClrError) as err:
+        read_mesh(fifo)
+    t.join()
+    assert 'not a regular file' in str(err.value)

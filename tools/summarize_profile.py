@@ -67,11 +67,11 @@ def main(tag, key):
     json.dump(summary, open(os.path.join(DST, tag + '_clr_render.json'), 'w'), indent=1)
     path = os.path.join(DST, 'pmc_traffic.json')
     table = json.load(open(path)) if os.path.exists(path) else {}
-    table[key] = fetch + write
+    table[key] = {'bytes_per_launch': fetch + write, 'source': 'profiles/%s_clr_render.json' % tag}
     json.dump(table, open(path, 'w'), indent=1)
     print(json.dumps(summary, indent=1))
 
 
 if __name__ == '__main__':
     main(sys.argv[1] if len(sys.argv) > 1 else 'r01',
-         sys.argv[2] if len(sys.argv) > 2 else 'scene-dev 1920x1080 p32')
+         sys.argv[2] if len(sys.argv) > 2 else 'scene-dev 1920x1080 p32 tape')
