@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument('--scene', default='scene-dev')
     ap.add_argument('--size', default='1920x1080')
     ap.add_argument('--mesh-grid', default='1000x500', help='scene-mesh: quads along / around the tube')
+    ap.add_argument('--mesh-overlap', choices=['sat', 'reference'], default='sat',
+                    help="scene-mesh: rule that files faces under octree leaves (same hits either way): "
+                         "'sat' triangle against box, 'reference' the reference's bounding-sphere rule")
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--regenerate', type=int, default=None, help='path regeneration 1/0 (default: on with --rng philox)')
     ap.add_argument('--rng', choices=['tape', 'philox'], default='tape',
@@ -150,7 +153,8 @@ def main():
         path = os.path.join(ROOT, 'raytracer_amd', 'scenes', args.scene + '.py')
         if args.scene == 'scene-mesh':
             n_u, n_v = (int(v) for v in args.mesh_grid.lower().split('x'))
-            scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout)
+            scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout,
+                                                                       overlap=args.mesh_overlap)
         else:
             scene = runpy.run_path(path)['scene']
         scene.image.size = (width, height)

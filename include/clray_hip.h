@@ -176,6 +176,13 @@ typedef struct clr_octree_info_t {
 
 int clr_octree_build(const float *vertices, int n_vertices, const int *faces, int n_faces,
                      int max_depth, int max_faces_per_leaf, clr_octree **out);
+/* The same with a choice of the rule that files a face under a node.  overlap_rule 0: the
+ * reference's (objects/octree.py:201-233: bounding sphere of the face against bounding sphere of
+ * the node, and the node sphere must reach the face's plane), which reproduces the reference's
+ * tree and stream.  overlap_rule 1: the triangle itself against the node's box (separating-axis
+ * test): the same hits from a tree with a fraction of the leaf records, for large meshes. */
+int clr_octree_build_rule(const float *vertices, int n_vertices, const int *faces, int n_faces,
+                          int max_depth, int max_faces_per_leaf, int overlap_rule, clr_octree **out);
 int clr_octree_info(const clr_octree *oct, clr_octree_info_t *info);
 /* Copies out whichever destinations are not NULL: the reference stream (stream_length ints),
  * the flattened nodes (2 ints per node) and triangle records (12 floats per record). */

@@ -99,6 +99,7 @@ def load_library():
         'clr_render_passes_static_log': (ci, [vp, P(RenderArgs), vp, P(ctypes.c_float)]),
         'clr_first_hit': (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
         'clr_octree_build': (ci, [vp, ci, vp, ci, ci, ci, P(vp)]),
+        'clr_octree_build_rule': (ci, [vp, ci, vp, ci, ci, ci, ci, P(vp)]),
         'clr_octree_info': (ci, [vp, P(OctreeInfo)]),
         'clr_octree_copy': (ci, [vp, vp, vp, vp]),
         'clr_octree_destroy': (ci, [vp]),
@@ -172,18 +173,25 @@ def unique_faces(faces):
     return kept[:n.value]
 
 
-def build_octree(vertices, faces, max_depth, max_faces_per_leaf):
+OVERLAP_RULES = {'reference': 0, 'sat': 1}
+
+
+def build_octree(vertices, faces, max_depth, max_faces_per_leaf, overlap='reference'):
     """Native (C++) octree construction; host only.  Returns a dict with the reference-format
-    node stream, the flattened nodes / triangle records and the root cube."""
+    node stream, the flattened nodes / triangle records and the root cube.
+    overlap: 'reference' = the reference's bounding-sphere rule (its tree, its stream), 'sat' =
+    exact triangle-box overlap (same hits, far fewer leaf records)."""
     lib = load_library()
     vertices = np.ascontiguousarray(vertices, dtype=np.float32)
     faces = np.ascontiguousarray(faces, dtype=np.int32)
     handle = ctypes.c_void_p()
-    rc = lib.clr_octree_build(vertices.ctypes.data_as(ctypes.c_void_p), vertices.shape[0],
-                              faces.ctypes.data_as(ctypes.c_void_p), faces.shape[0],
-                              int(max_depth), int(max_faces_per_leaf), ctypes.byref(handle))
+    rc = lib.clr_octree_build_rule(vertices.ctypes.data_as(ctypes.c_void_p), vertices.shape[0],
+                                   faces.ctypes.data_as(ctypes.c_void_p), faces.shape[0],
+                                   int(max_depth), int(max_faces_per_leaf), OVERLAP_RULES[overlap],
+                                   ctypes.byref(handle))
     if rc != 0:
-        raise ClrError("clr_octree_build: bad mesh or parameters (face index out of range, "
+        raise ClrError("clr_octree_build: out of memory" if rc == 2 else
+                       "clr_octree_build: bad mesh or parameters (face index out of range, "
                        "max_depth outside 0..20)")
     try:
         info = OctreeInfo()
@@ -196,6 +204,7 @@ def build_octree(vertices, faces, max_depth, max_faces_per_leaf):
     finally:
         lib.clr_octree_destroy(handle)
     return {'stream': stream, 'root_data_offset': info.root_data_offset, 'flat_nodes': nodes,
+            'leaf_records': info.flat_triangles,
             'flat_tris': tris, 'root_origin': np.array(info.root_origin[:]), 'root_size': info.root_size,
             'n_nodes': info.n_nodes, 'n_leaves': info.n_leaves, 'max_depth': info.max_depth}
 

@@ -9,6 +9,14 @@
 // only against its parent's faces is equivalent: the child's bounding sphere lies inside the
 // parent's, so the overlap predicate is monotone.
 //
+// Second overlap rule, for throughput (clr_octree_build_rule, rule 1): a face belongs to a node
+// when the TRIANGLE intersects the node's box (separating-axis test of Akenine-Moeller 2001, box
+// widened by a small margin against rounding).  The bounding-sphere rule above files a face of a
+// fine mesh under a dozen leaves it never touches (12.7 leaf records per face on the 1 M-triangle
+// knot); the exact rule changes which leaves list a face, not which face a ray hits: the
+// traversal accepts a hit only up to the leaf's exit distance, such a hit point lies inside the
+// leaf's box, so the face intersects the box and is listed there under either rule.
+//
 // Two serialisations: the reference's integer stream (objects/octree.py:119-156), used for
 // parity with the reference layout, and a flattened layout for the HIP traversal kernel:
 //   nodes: int2 per node, children of an inner node contiguous;
@@ -53,6 +61,7 @@ struct Builder {
     const float *v;
     const int *f;
     int n_faces, max_depth, max_leaf;
+    int rule = 0;                      // 0: the reference's bounding-sphere rule, 1: triangle-box
     std::vector<double> cx, cy, cz, rad, nx, ny, nz, h;
     clr_octree *out;
 
@@ -81,7 +90,47 @@ struct Builder {
         }
     }
 
+    // exact triangle / axis-aligned box overlap: 3 box axes, the face normal, 9 edge cross products
+    bool triangle_touches_box(const Node &node, int face) const {
+        const double margin = 1e-6;                        // relative widening of the box
+        const double half = node.size * 0.5 * (1.0 + margin) + 1e-12;
+        double p[3][3];
+        for (int k = 0; k < 3; ++k)
+            for (int d = 0; d < 3; ++d)
+                p[k][d] = (double)v[3 * f[3 * face + k] + d] - (node.origin[d] + node.size * 0.5);
+        for (int d = 0; d < 3; ++d) {
+            const double lo = std::fmin(p[0][d], std::fmin(p[1][d], p[2][d]));
+            const double hi = std::fmax(p[0][d], std::fmax(p[1][d], p[2][d]));
+            if (lo > half || hi < -half) return false;
+        }
+        const double n[3] = {nx[face], ny[face], nz[face]};
+        const double dist = n[0] * p[0][0] + n[1] * p[0][1] + n[2] * p[0][2];
+        if (std::fabs(dist) > half * (std::fabs(n[0]) + std::fabs(n[1]) + std::fabs(n[2]))) return false;
+        for (int e = 0; e < 3; ++e) {
+            double edge[3];
+            for (int d = 0; d < 3; ++d) edge[d] = p[(e + 1) % 3][d] - p[e][d];
+            for (int a = 0; a < 3; ++a) {
+                // axis = unit vector a x edge
+                double axis[3] = {0, 0, 0};
+                const int b = (a + 1) % 3, c = (a + 2) % 3;
+                axis[b] = -edge[c];
+                axis[c] = edge[b];
+                double lo = 0, hi = 0;
+                for (int k = 0; k < 3; ++k) {
+                    const double s = axis[0] * p[k][0] + axis[1] * p[k][1] + axis[2] * p[k][2];
+                    if (k == 0 || s < lo) lo = s;
+                    if (k == 0 || s > hi) hi = s;
+                }
+                const double r = half * (std::fabs(axis[0]) + std::fabs(axis[1]) + std::fabs(axis[2]));
+                const double slack = 1e-9 * (std::fabs(lo) + std::fabs(hi) + r);
+                if (lo > r + slack || hi < -r - slack) return false;
+            }
+        }
+        return true;
+    }
+
     bool overlaps(const Node &node, int face) const {
+        if (rule == 1) return triangle_touches_box(node, face);
         const double half = node.size * 0.5;
         const double c[3] = {node.origin[0] + half, node.origin[1] + half, node.origin[2] + half};
         const double r = std::sqrt(3.0) * node.size * 0.5;
@@ -201,12 +250,21 @@ extern "C" {
 
 int clr_octree_build(const float *vertices, int n_vertices, const int *faces, int n_faces,
                      int max_depth, int max_faces_per_leaf, clr_octree **out) {
-    if (!vertices || !faces || !out || n_vertices <= 0 || n_faces <= 0 || max_depth < 0 || max_depth > 20)
+    return clr_octree_build_rule(vertices, n_vertices, faces, n_faces, max_depth, max_faces_per_leaf, 0, out);
+}
+
+int clr_octree_build_rule(const float *vertices, int n_vertices, const int *faces, int n_faces,
+                          int max_depth, int max_faces_per_leaf, int overlap_rule, clr_octree **out) {
+    if (!vertices || !faces || !out || n_vertices <= 0 || n_faces <= 0 || max_depth < 0 || max_depth > 20 ||
+        overlap_rule < 0 || overlap_rule > 1)
         return 1;
     for (int i = 0; i < 3 * n_faces; ++i)
         if (faces[i] < 0 || faces[i] >= n_vertices) return 1;
-    clr_octree *oct = new clr_octree;
+    clr_octree *oct = nullptr;
+    try {                                  // no C++ exception (allocation failure) may cross the C boundary
+    oct = new clr_octree;
     Builder b;
+    b.rule = overlap_rule;
     b.v = vertices; b.f = faces; b.n_faces = n_faces; b.max_depth = max_depth; b.max_leaf = max_faces_per_leaf;
     b.out = oct;
     // bounding cube of the binary32 vertices (triangle_mesh.py:54-69), widened by 1 % (octree.py:71-74)
@@ -244,6 +302,10 @@ int clr_octree_build(const float *vertices, int n_vertices, const int *faces, in
     oct->stream.push_back(header[0]);
     oct->stream.push_back(header[1]);
     b.flatten();
+    } catch (...) {
+        delete oct;
+        return 2;
+    }
     *out = oct;
     return 0;
 }

@@ -106,7 +106,7 @@ class Octree(Tracer):
     MAX_DEPTH = 7
 
     def __init__(self, triangle_mesh, max_depth=3, max_faces_per_leaf=5, builder='python',
-                 layout='stream', max_steps=300, pooled=None):
+                 layout='stream', max_steps=300, pooled=None, overlap='reference'):
         """builder: 'python' (restatement of the reference's construction) or 'native' (C++
         builder of libclray_hip.so, same tree, any size, max_depth up to 20).
         layout: 'stream' = the reference's integer stream; 'flat' = flattened nodes + per-leaf
@@ -114,7 +114,15 @@ class Octree(Tracer):
         max_steps: leaf-step budget of the traversal (300 in the reference).
         pooled (flat layout only, default on): the triangle tests of all lanes of a wave are
         pooled and dealt out evenly, so lanes whose ray left the mesh or sits in a small leaf
-        work on the leaves of the others (same tests, same results)."""
+        work on the leaves of the others (same tests, same results).
+        overlap (native builder): 'reference' = the reference's bounding-sphere rule for filing a
+        face under a node (objects/octree.py:201-233), 'sat' = the triangle against the node's box:
+        same hits, a fraction of the leaf records (for large meshes)."""
+        if overlap not in ('reference', 'sat'):
+            raise ValueError("overlap must be 'reference' or 'sat'")
+        if overlap != 'reference' and builder == 'python' and layout != 'flat':
+            raise RuntimeError("overlap='sat' needs the native builder")
+        self.overlap = overlap
         if layout == 'flat':
             builder = 'native'
         self.pooled = (layout == 'flat') if pooled is None else bool(pooled)
@@ -233,7 +241,8 @@ class Octree(Tracer):
         import types
         from ..accelerator import build_octree
         mesh = self.triangle_mesh
-        self._native = build_octree(mesh.vertices, mesh.faces, self.max_depth, self.max_faces_per_leaf)
+        self._native = build_octree(mesh.vertices, mesh.faces, self.max_depth, self.max_faces_per_leaf,
+                                    overlap=self.overlap)
         self.root = types.SimpleNamespace(origin=self._native['root_origin'], size=self._native['root_size'])
         self.origin, self.size = self.root.origin, self.root.size
         self.n_leaves = self._native['n_leaves']

@@ -349,7 +349,10 @@ def torus_knot_mesh(n_u=1000, n_v=500, tube=0.45, bump=0.05):
 
 
 def scene_mesh(n_u=1000, n_v=500, layout='flat', max_depth=None, max_faces_per_leaf=8,
-               max_steps=2000, material='white', pooled=None):
+               max_steps=2000, material='white', pooled=None, overlap='sat'):
+    """overlap: how the builder files faces under leaves - 'sat' (triangle against box, 3.0 leaf
+    records per face on this mesh) or 'reference' (the reference's bounding-sphere rule, 12.7);
+    the hits are the same (tests/test_gpu_parity.py)."""
     s = BoxScene()
     s.get_object('light').bidirectional_light = True
     vertices, faces = torus_knot_mesh(n_u, n_v)
@@ -358,7 +361,8 @@ def scene_mesh(n_u=1000, n_v=500, layout='flat', max_depth=None, max_faces_per_l
     mesh = TriangleMesh(vertices, faces, auto_scale=True, center=(0, 0, 1), scale=1.0,
                         auto_flip_normal=True)
     s.add_object(Octree(mesh, max_depth=max_depth, max_faces_per_leaf=max_faces_per_leaf,
-                        builder='native', layout=layout, max_steps=max_steps, pooled=pooled), material, 'knot')
+                        builder='native', layout=layout, max_steps=max_steps, pooled=pooled,
+                        overlap=overlap), material, 'knot')
     s.image.size = (1920, 1080)
     s.samples_per_pixel = 16
     s.max_bounces = 4

@@ -33,14 +33,17 @@ def load_scene(name, size=None, **overrides):
                                     Affine=Affine, Cube=shapes.Cube, Sphere=shapes.Sphere,
                                     Cylinder=shapes.Cylinder, HalfSpace=shapes.HalfSpace)
         scene = golden_scenes.VARIANTS[name](api)
-    elif name.startswith('scene-mesh'):      # 'scene-mesh:<n_u>x<n_v>:<layout>', layout 'flat-lanes' = flat, not pooled
-        _, grid, layout = (name.split(':') + ['120x60', 'flat'])[:3] if ':' in name else (name, '120x60', 'flat')
+    elif name.startswith('scene-mesh'):
+        # 'scene-mesh:<n_u>x<n_v>:<layout>:<overlap>', layout 'flat-lanes' = flat, not pooled;
+        # overlap 'reference' (default here: the reference's tree) or 'sat'
+        _, grid, layout, overlap = (name.split(':') + ['120x60', 'flat', 'reference'])[:4] if ':' in name \
+            else (name, '120x60', 'flat', 'reference')
         n_u, n_v = (int(v) for v in grid.split('x'))
         make = runpy.run_path(os.path.join(SCENE_DIR, 'scene-mesh.py'), run_name='lib')['make_scene']
         if layout == 'flat-lanes':
-            scene = make(n_u, n_v, layout='flat', pooled=False)
+            scene = make(n_u, n_v, layout='flat', pooled=False, overlap=overlap)
         else:
-            scene = make(n_u, n_v, layout=layout)
+            scene = make(n_u, n_v, layout=layout, overlap=overlap)
     else:
         scene = runpy.run_path(os.path.join(SCENE_DIR, name + '.py'))['scene']
     if size is not None:

@@ -546,3 +546,47 @@ def test_pass_split_arguments_must_match_the_program():
     with pytest.raises(Exception) as err:
         small.render_tape(small.make_tape(0, 1))
     assert 'pass_log' in str(err.value)
+
+
+def test_triangle_box_tree_gives_the_same_image_as_the_reference_tree():
+    """overlap='sat' changes which leaves list a face, not what a ray hits: 14 400 triangles,
+    flattened layout, pooled tests - first hits and a 4-pass image equal the reference-rule tree's
+    and the oracle's (which walks the reference stream of the reference-rule tree) bit for bit."""
+    from oracle import oracle
+    sat = Renderer(load_scene('scene-mesh:120x60:flat:sat', (96, 64)), seed=4)
+    ref = Renderer(load_scene('scene-mesh:120x60:stream:reference', (96, 64)), seed=4)
+    knot = [o for o in sat.scene.objects if o.name == 'knot'][0].tracer
+    knot_ref = [o for o in ref.scene.objects if o.name == 'knot'][0].tracer
+    assert knot._native['leaf_records'] < 0.3 * knot_ref._native['leaf_records']
+    osc = oracle.OracleScene(ref)
+    tape = sat.make_tape(0, 4)
+    one = tuple(x[:1] if x is not None else None for x in tape)
+    ids, t, n = sat.first_hit(one)
+    ids_o, t_o, n_o = osc.first_hit(one)
+    assert np.array_equal(ids, ids_o) and np.array_equal(bits(t), bits(t_o)) and np.array_equal(bits(n), bits(n_o))
+    sat.render_tape(tape)
+    oimg, _, _ = osc.render(tape)
+    assert np.array_equal(bits(sat.img.get()), bits(oimg))
+
+
+def test_one_million_triangles_pooled_per_lane_and_both_trees_agree():
+    """BASELINE config C4 at its real size (1 M triangles, 1920 x 1080): size-independent
+    properties.  First-hit ids, distances and normals of the full frame are bit-identical between
+    the pooled and the per-lane triangle tests and between the triangle-box tree and the
+    reference-rule tree; a 2-pass image is bit-identical between pooled and per-lane."""
+    results, images = [], []
+    for layout, overlap in (('flat', 'sat'), ('flat-lanes', 'sat'), ('flat', 'reference')):
+        r = Renderer(load_scene('scene-mesh:1000x500:%s:%s' % (layout, overlap), (1920, 1080)), seed=9)
+        tape = r.make_tape(0, 2)
+        results.append(r.first_hit(tuple(x[:1] if x is not None else None for x in tape)))
+        if overlap == 'sat':
+            r.render_tape(tape)
+            images.append(r.img.get())
+        del r
+    ids0, t0, n0 = results[0]
+    knot = ids0[:, 0] == np.bincount(ids0[:, 0]).argmax()      # may be a wall; just need both classes
+    assert 0 < knot.mean() < 1 and len(np.unique(ids0[:, 1])) > 10000    # thousands of distinct faces seen
+    for ids, t, n in results[1:]:
+        assert np.array_equal(ids, ids0) and np.array_equal(bits(t), bits(t0)) and np.array_equal(bits(n), bits(n0))
+    assert images[0][:, :3].mean() > 0
+    assert np.array_equal(bits(images[0]), bits(images[1]))

@@ -346,3 +346,86 @@ def test_pass_split_launches_are_cut_to_bound_the_addend_log():
     r.acc = Acc()
     ms, _ = r.render_tape(r.make_tape(0, 8), first_pass=10)
     assert calls == [(3, 10), (3, 13), (2, 16)] and ms == 3.0
+
+
+def _leaf_boxes(native):
+    """(origin, size, first record, count) of every leaf of a flattened native tree."""
+    nodes, out = native['flat_nodes'], []
+    stack = [(0, np.asarray(native['root_origin'], float), float(native['root_size']))]
+    while stack:
+        index, origin, size = stack.pop()
+        a, b = nodes[index]
+        if a >= 0:
+            out.append((origin, size, b, a))
+            continue
+        for k in range(8):
+            xyz = np.array([(k >> 2) & 1, (k >> 1) & 1, k & 1], float)
+            stack.append((b + k, origin + xyz * 0.5 * size, 0.5 * size))
+    return out
+
+
+@pytest.mark.parametrize('n,depth,leaf', [(400, 4, 5), (1500, 5, 4)])
+def test_triangle_box_overlap_rule_gives_a_tighter_tree_that_misses_nothing(n, depth, leaf):
+    """overlap='sat' (no counterpart in the reference, whose rule is objects/octree.py:201-233):
+    every leaf lists a subset of what the reference rule lists for the same box, and every
+    triangle that really reaches into a leaf's box - checked by sampling points of the triangle -
+    is listed there, which is what the traversal needs (it accepts hits inside the leaf only)."""
+    from raytracer_amd import accelerator
+    vertices, faces = random_triangle_soup(n, seed=n + 1)
+    v32 = np.float32(vertices)
+    ref = accelerator.build_octree(v32, faces, depth, leaf, overlap='reference')
+    sat = accelerator.build_octree(v32, faces, depth, leaf, overlap='sat')
+    assert sat['leaf_records'] < 0.7 * ref['leaf_records']
+    ids = lambda tree, first, count: set(tree['flat_tris'].reshape(-1, 3, 4)[first:first + count, 0, 3].copy().view(np.int32))
+    ref_leaves = {(tuple(np.round(o, 9)), round(s, 9)): ids(ref, f, c) for o, s, f, c in _leaf_boxes(ref)}
+    rng = np.random.RandomState(5)
+    w = rng.dirichlet((1, 1, 1), size=60)                        # points of a triangle
+    tri = v32[faces].astype(float)                               # (n, 3, 3)
+    points = np.einsum('sk,nkd->nsd', w, tri)                    # (n, 60, 3)
+    checked = 0
+    for origin, size, first, count in _leaf_boxes(sat):
+        listed = ids(sat, first, count)
+        # a SAT leaf may be a coarser node than the reference tree's leaves (fewer faces -> it
+        # stops splitting earlier); where the same box is a leaf of both, SAT lists a subset
+        key = (tuple(np.round(origin, 9)), round(size, 9))
+        if key in ref_leaves:
+            assert listed <= ref_leaves[key]
+            checked += 1
+        inside = ((points >= origin) & (points <= origin + size)).all(axis=2).any(axis=1)
+        assert set(np.flatnonzero(inside)) <= listed
+    assert checked > 10
+
+
+def test_octree_hits_equal_brute_force_under_both_overlap_rules():
+    """first hits through the octree (oracle walking the reference stream of the
+    reference-rule tree and of the triangle-box tree) equal a brute-force sweep over all faces
+    of the same mesh: same face, same distance bits."""
+    from oracle import oracle
+    from raytracer_amd.scenes.library import BoxScene, torus_knot_mesh
+    vertices, faces = torus_knot_mesh(60, 40)                    # 4800 triangles
+
+    def scene_with(make_tracer):
+        s = BoxScene()
+        mesh = shapes.TriangleMesh(vertices, faces, auto_scale=True, center=(0, 0, 1), scale=1.0,
+                                   auto_flip_normal=True)
+        s.add_object(make_tracer(mesh), 'white', 'knot')
+        s.image.size = (96, 64)
+        s.camera_position = (1.5, -4.2, 2.2)
+        s.direct_camera_towards((0, 0, 0.9))
+        return s
+    results = []
+    for make_tracer in (lambda m: m,
+                        lambda m: shapes.Octree(m, max_depth=5, max_faces_per_leaf=6, builder='native'),
+                        lambda m: shapes.Octree(m, max_depth=5, max_faces_per_leaf=6, builder='native', overlap='sat')):
+        r = Renderer(scene_with(make_tracer), device=False, seed=2)
+        ids, t, normal = oracle.OracleScene(r).first_hit(r.make_tape(0, 1))
+        # objects are numbered after sorting by class name, so the knot's id depends on its class
+        knot_id = [o.name for o in r.scene.objects].index('knot') + 1
+        results.append((ids[:, 0] == knot_id, ids[:, 1], t, normal))
+    on_knot = results[0][0]
+    assert on_knot.mean() > 0.1
+    for hit, face, t, normal in results[1:]:
+        assert np.array_equal(hit, on_knot)
+        assert np.array_equal(face[on_knot], results[0][1][on_knot])
+        assert np.array_equal(t.view(np.uint32), results[0][2].view(np.uint32))
+        assert np.array_equal(normal.view(np.uint32), results[0][3].view(np.uint32))

@@ -6,7 +6,8 @@
 # Results land in gpurun_out/prof/; tools/summarize_profile.py condenses them into profiles/.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof
+OUT=$R/gpurun_out/${PROFILE_OUT:-prof}
+rm -rf $OUT/trace $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_grbm
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu-baseline $PROFILE_ARGS"

@@ -25,7 +25,10 @@ def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 
-def main(tag, key):
+def main(tag, key, src=None):
+    global SRC
+    if src:
+        SRC = os.path.join(ROOT, 'gpurun_out', src)
     os.makedirs(DST, exist_ok=True)
     stats = newest(os.path.join(SRC, 'trace', '*', '*_kernel_stats.csv'))
     shutil.copy(stats, os.path.join(DST, tag + '_kernel_stats.csv'))
@@ -74,4 +77,5 @@ def main(tag, key):
 
 if __name__ == '__main__':
     main(sys.argv[1] if len(sys.argv) > 1 else 'r01',
-         sys.argv[2] if len(sys.argv) > 2 else 'scene-dev 1920x1080 p32 tape')
+         sys.argv[2] if len(sys.argv) > 2 else 'scene-dev 1920x1080 p32 tape',
+         sys.argv[3] if len(sys.argv) > 3 else None)
