@@ -118,7 +118,8 @@ typedef struct clr_render_args {
     const void *integer_data;  /* mesh faces / octree stream (int32) or NULL */
     int n_pixels;
     int n_passes;
-    int regenerate;            /* 1: a lane starts its next pass as soon as its path ends */
+    int regenerate;            /* 1: a lane starts its next pass as soon as its path ends; must say which
+                                * form of clr_render the program holds (module global clr_regen_mode) */
     void *debug_dump;          /* optional: max_bounces x n_pixels x 6 float4 (n_passes must be 1) */
     /* per-pixel random numbers (programs generated with rng_mode 'philox'; no counterpart in the
      * reference, whose random numbers are per frame): Philox key, global index of the first pass

@@ -67,6 +67,7 @@ struct clr_program {
     int rng_mode;      // 1: the program draws per-pixel random numbers, 0: it reads the bounce tape
     int split_mode;    // 1: clr_render logs addends per pass and clr_reduce_log sums them
     int log_floats;    // floats per (pass, pixel) of the addend log (module global clr_log_floats)
+    int regen_mode;    // 1: regenerating form of clr_render, 0: lock-step form, -1: not stated
 };
 
 namespace {
@@ -273,6 +274,9 @@ int load_program(clr_ctx *ctx, const void *binary, clr_program **out) {
         (void)hipMemcpyDtoH(&prog->rng_mode, flag, sizeof(int));
     if (hipModuleGetGlobal(&flag, &flag_size, prog->module, "clr_split_mode") == hipSuccess && flag_size == sizeof(int))
         (void)hipMemcpyDtoH(&prog->split_mode, flag, sizeof(int));
+    prog->regen_mode = -1;
+    if (hipModuleGetGlobal(&flag, &flag_size, prog->module, "clr_regen_mode") == hipSuccess && flag_size == sizeof(int))
+        (void)hipMemcpyDtoH(&prog->regen_mode, flag, sizeof(int));
     prog->log_floats = 0;
     if (hipModuleGetGlobal(&flag, &flag_size, prog->module, "clr_log_floats") == hipSuccess && flag_size == sizeof(int))
         (void)hipMemcpyDtoH(&prog->log_floats, flag, sizeof(int));
@@ -378,6 +382,8 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     if (!prog->rng_mode && !a->bounce_tape)
         return fail("clr_render_passes: bounce_tape is required for a tape program");
     if (a->pass_stride < 0) return fail("clr_render_passes: pass_stride must not be negative");
+    if (prog->regen_mode >= 0 && (a->regenerate != 0) != (prog->regen_mode != 0))
+        return fail("clr_render_passes: `regenerate` does not match the form of clr_render the program was generated in");
     if (a->debug_dump && a->n_passes != 1)
         return fail("clr_render_passes: debug_dump needs n_passes == 1");
     if (static_log) {
@@ -421,7 +427,8 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
         return launch(prog->ctx, prog->render, grid, block, args, stream, elapsed_ms);
     }
     // pass-split program: n_pixels x pass_groups lanes write the log, then one lane per pixel sums it
-    const unsigned long long lanes = (unsigned long long)n_pixels * (unsigned)pass_groups;
+    // whole waves per group, so that no wave straddles two groups (main.hip)
+    const unsigned long long lanes = (((unsigned long long)n_pixels + 63) & ~63ull) * (unsigned)pass_groups;
     if (lanes > 0x7fffffffull) return fail("clr_render_passes: n_pixels x pass_groups is too large");
     const unsigned grid[3] = {(unsigned)((lanes + kBlock - 1) / kBlock), 1, 1};
     const unsigned reduce_grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};

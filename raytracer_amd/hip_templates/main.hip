@@ -34,6 +34,9 @@ __constant__ int clr_rng_mode = {{ 1 if renderer.rng_mode == 'philox' else 0 }};
 // 1: pass-split program (clr_render writes a log of addends per pass, clr_reduce_log sums it);
 // read by the host library like clr_rng_mode
 __constant__ int clr_split_mode = {{ 1 if renderer.split_passes else 0 }};
+// 1: regenerating form of clr_render, 0: lock-step form; read by the host library, which checks
+// the `regenerate` launch argument against it
+__constant__ int clr_regen_mode = {{ 1 if renderer.regenerate else 0 }};
 #define CLR_LOG_FLOATS {{ 1 + 6*renderer.scene.max_bounces }}   // per (pass, pixel): header word, then <= 2 addends of 3 floats per segment
 __constant__ int clr_log_floats = CLR_LOG_FLOATS;              // read by the host library (size check of the static log)
 ### if renderer.rng_mode == 'philox'
@@ -297,17 +300,37 @@ static __device__ __attribute__((noinline)) bool clr_segment_generic(PathState *
 
 // ---------------------------------------------------------------------------------------
 // Render kernel.  Lane k owns pixel k (blocked pixel order) and accumulates its radiance in
-// registers over `n_passes` sample passes; img[k] is read once and written once.
-//   regen = 0: the lanes of a wave start each pass together (finished paths idle until the
-//              slowest path of the wave ends);
-//   regen = 1: a lane starts its next pass as soon as its path ends, so every lane of the wave
-//              always executes a live segment (path regeneration).  Per-pixel results are
-//              identical in both modes: a lane still visits its passes and segments in order.
+// registers over `n_passes` sample passes; img[k] is read once and written once.  Two program
+// forms (clr_regen_mode; per-pixel results are identical, a lane visits its passes and segments
+// in the same order in both):
+//   lock-step (default with the broadcast tape): the lanes of a wave start each pass together, so
+//       pass and segment numbers are wave-uniform: they live in scalar registers, and the tape
+//       records of a pass / a segment arrive through scalar loads into scalar registers instead
+//       of 20 + 20 vector registers per lane.  Finished paths idle until the slowest path of the
+//       wave ends (with the broadcast tape all lanes take the same stochastic decisions and
+//       finish together).
+//   regenerating (default with per-pixel random numbers): a lane starts its next pass as soon as
+//       its path ends, so every lane of the wave always executes a live segment.
 // dbg (optional, n_passes == 1): CLR_DBG_STRIDE float4 per (segment, pixel).
-// Pass-split programs (clr_split_mode, small frames): n_pixels x pass_groups lanes; a lane walks a
-// range of the passes of its pixel and logs its addends instead of summing them (clr_acc), img is
-// left to clr_reduce_log.
+// Pass-split programs (clr_split_mode, small frames): n_padded x pass_groups lanes, n_padded =
+// n_pixels rounded up to whole waves, so that a wave never straddles two groups; a lane walks a
+// range of the passes of its pixel and logs its addends instead of summing them (clr_acc), img
+// is left to clr_reduce_log.
 // ---------------------------------------------------------------------------------------
+{%- macro run_segment(pass, segment) %}
+            const bool is_last = {{ segment }} == CLR_MAX_BOUNCES - 1;
+### if renderer.rng_mode == 'philox'
+            // the light sample feeds the visibility test and the diffuse stage, both of which
+            // need a diffuse bounce to be left and are skipped on the last segment
+            const BounceSample B = clr_draw_bounce(rng_seed_lo, rng_seed_hi, (uint)(first_ray + k),
+                                                   (uint)(first_pass + {{ pass }} * pass_stride), (uint){{ segment }},
+                                                   !is_last && s.diffusions_left > 0);
+### else
+            const BounceSample B = clr_load_bounce(bounce_tape + ((size_t){{ pass }} * CLR_MAX_BOUNCES + {{ segment }}) * CLR_BOUNCE_STRIDE);
+### endif
+            float4 *d = dbg ? dbg + ((size_t){{ segment }} * n_pixels + k) * CLR_DBG_STRIDE : nullptr;
+            const float *material_row = material_rows + (size_t){{ pass }} * CLR_MATERIAL_ROW;
+{%- endmacro %}
 extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_per_simd if renderer.min_waves_per_simd else '' }})
 clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
            const float4 * __restrict__ pass_tape, const float4 * __restrict__ bounce_tape,
@@ -321,12 +344,14 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
     // pass-split mode: lane (k, group) walks the passes [group * per_group, ...) of pixel k and
     // logs what it would have added to the pixel (layout: clr_acc, shader.hip)
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = lane % n_pixels, group = lane / n_pixels;
-    const bool in_image = group < pass_groups;
+    const int n_padded = (n_pixels + 63) & ~63;
+    const int k = lane % n_padded;
+    const int group = __builtin_amdgcn_readfirstlane(lane / n_padded);      // the same for a whole wave
+    const bool in_image = group < pass_groups && k < n_pixels;
     const int per_group = (n_passes + pass_groups - 1) / pass_groups;
-    const int pass_begin = in_image ? min(group * per_group, n_passes) : n_passes;
-    const int pass_end = in_image ? min(pass_begin + per_group, n_passes) : n_passes;
-    const int kk = k;
+    const int pass_begin = group < pass_groups ? min(group * per_group, n_passes) : n_passes;
+    const int pass_end = group < pass_groups ? min(pass_begin + per_group, n_passes) : n_passes;
+    const int kk = in_image ? k : 0;
     const vec3 base_ray = make_vec3(cam[kk]);
 ### else
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,56 +371,106 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
     clr_acc acc;
 ### if renderer.split_passes
     acc.stride = (size_t)n_pixels;
-    acc.begin_pass(pass_log, 0, k);
+    acc.begin_pass(pass_log, 0, kk);
 ### else
     acc.v = make_vec3(img0.x, img0.y, img0.z);
 ### endif
 
     PathState s;
+    vec3 cmask = make_vec3(1.0f, 1.0f, 1.0f);
+### if renderer.speculate and not renderer.split_passes
+    vec3 acc_at_pass_start = acc.v;
+### endif
+
+### if not renderer.regenerate
+    // ---- lock-step form
+    for (int pass = pass_begin; pass < pass_end; ++pass) {
+        const float4 *rec = pass_tape + (size_t)pass * CLR_PASS_STRIDE;
+        clr_start_path(s, rec, base_ray);
+        cmask = make_vec3(rec[5]);
+        bool active = in_image;
+    ### if renderer.split_passes
+        acc.begin_pass(pass_log, pass, kk);
+    ### endif
+    ### if renderer.speculate
+        ### if not renderer.split_passes
+        acc_at_pass_start = acc.v;
+        ### endif
+        // a lane whose operands left the range of the speculative arithmetic abandons the pass
+        // and walks it again below with the generic arithmetic
+        bool redo = false;
+    ### endif
+        for (int segment = 0; segment < CLR_MAX_BOUNCES; ++segment) {
+            if (!__any(active)) break;
+            if (active) {
+                {{ run_segment('pass', 'segment') }}
+    ### if renderer.speculate
+                clr_guard_spec spec;
+                clr_guard_reset(spec);
+                bool alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, spec);
+                if (!clr_guard_ok(spec)) { redo = true; alive = false; }
+    ### else
+                const bool alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, clr_g);
+    ### endif
+                active = alive;
+            }
+        }
+    ### if renderer.speculate
+        if (__any(redo)) {                      // rare (none on scene-dev, 2e-6 per sample on scene-three-objects)
+            if (redo) {
+        ### if renderer.split_passes
+                acc.restart_pass();
+        ### else
+                acc.v = acc_at_pass_start;
+        ### endif
+                clr_start_path(s, rec, base_ray);
+                for (int segment = 0; segment < CLR_MAX_BOUNCES; ++segment) {
+                    {{ run_segment('pass', 'segment') }}
+                    // only copies of the state escape to the callee
+                    PathState s1 = s;
+                    clr_acc acc1 = acc;
+                    BounceSample B1 = B;
+                    const bool alive = clr_segment_generic(&s1, &B1, is_last, cmask, &acc1, material_row, vector_data, integer_data, d);
+                    s = s1;
+                    acc = acc1;
+                    if (!alive) break;
+                }
+            }
+        }
+    ### endif
+    ### if renderer.split_passes
+        if (in_image) acc.end_pass();
+    ### endif
+    }
+### else
+    // ---- regenerating form: every lane is its own little state machine
     int pass = in_image ? pass_begin : pass_end;
     int segment = 0;
     bool active = false;
-    vec3 cmask = make_vec3(1.0f, 1.0f, 1.0f);
-### if renderer.speculate
-    ### if not renderer.split_passes
-    vec3 acc_at_pass_start = acc.v;
-    ### endif
+    ### if renderer.speculate
     bool generic_path = false;
-### endif
-
+    ### endif
     for (;;) {
-        const bool wave_busy = __any(active);
-        if (!active && pass < pass_end && (regen || !wave_busy)) {
+        if (!active && pass < pass_end) {
             const float4 *rec = pass_tape + (size_t)pass * CLR_PASS_STRIDE;
             clr_start_path(s, rec, base_ray);
             cmask = make_vec3(rec[5]);
             segment = 0;
             active = true;
-### if renderer.split_passes
-            acc.begin_pass(pass_log, pass, k);
-### endif
-### if renderer.speculate
-    ### if not renderer.split_passes
-            acc_at_pass_start = acc.v;
+    ### if renderer.split_passes
+            acc.begin_pass(pass_log, pass, kk);
     ### endif
+    ### if renderer.speculate
+        ### if not renderer.split_passes
+            acc_at_pass_start = acc.v;
+        ### endif
             generic_path = false;
-### endif
+    ### endif
         }
         if (!__any(active)) break;
         if (active) {
-            const bool is_last = segment == CLR_MAX_BOUNCES - 1;
-### if renderer.rng_mode == 'philox'
-            // the light sample feeds the visibility test and the diffuse stage, both of which
-            // need a diffuse bounce to be left and are skipped on the last segment
-            const BounceSample B = clr_draw_bounce(rng_seed_lo, rng_seed_hi, (uint)(first_ray + k),
-                                                   (uint)(first_pass + pass * pass_stride), (uint)segment,
-                                                   !is_last && s.diffusions_left > 0);
-### else
-            const BounceSample B = clr_load_bounce(bounce_tape + ((size_t)pass * CLR_MAX_BOUNCES + segment) * CLR_BOUNCE_STRIDE);
-### endif
-            float4 *d = dbg ? dbg + ((size_t)segment * n_pixels + k) * CLR_DBG_STRIDE : nullptr;
-            const float *material_row = material_rows + (size_t)pass * CLR_MATERIAL_ROW;
-### if renderer.speculate
+            {{ run_segment('pass', 'segment') }}
+    ### if renderer.speculate
             // Speculative arithmetic first.  If an operand leaves the range in which it is exact,
             // the lane takes the radiance it had at the start of the pass, starts the path of
             // this pass again and walks it with the generic arithmetic (rare; out of line).
@@ -405,11 +480,11 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
                 clr_guard_reset(spec);
                 alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, spec);
                 if (!clr_guard_ok(spec)) {
-    ### if renderer.split_passes
+        ### if renderer.split_passes
                     acc.restart_pass();
-    ### else
+        ### else
                     acc.v = acc_at_pass_start;
-    ### endif
+        ### endif
                     clr_start_path(s, pass_tape + (size_t)pass * CLR_PASS_STRIDE, base_ray);
                     segment = 0;
                     generic_path = true;
@@ -425,19 +500,20 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
                 s = s1;
                 acc = acc1;
             }
-### else
+    ### else
             const bool alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, clr_g);
-### endif
+    ### endif
             segment++;
             if (!alive) {
-### if renderer.split_passes
+    ### if renderer.split_passes
                 acc.end_pass();
-### endif
+    ### endif
                 active = false;
                 pass++;
             }
         }
     }
+### endif
 ### if not renderer.split_passes
     if (in_image) img[k] = make_float4(acc.v.x, acc.v.y, acc.v.z, img0.w);
 ### endif

@@ -73,7 +73,8 @@ class Renderer:
 
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
-                 min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None):
+                 min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None,
+                 regenerate=None):
         self.scene = scene
         # tile partitioning: (first ray, count) in ray order; a contiguous range of ray
         # indices is a set of 4-pixel-wide column blocks of the frame (get_image_order)
@@ -130,17 +131,32 @@ class Renderer:
         self.min_waves_per_simd = min_waves_per_simd
         # small scenes: bake the per-object parameters into the program text as literals
         self.bake_parameters = len(scene.objects) <= 48 if bake_parameters is None else bake_parameters
+        # path regeneration (main.hip): identical results; no gain while all pixels share their
+        # random numbers (lock-step then keeps pass and segment in scalar registers and reads the
+        # tape through scalar loads), +26..44 % once every pixel draws its own
+        self._regenerate = (self.rng_mode == 'philox') if regenerate is None else bool(regenerate)
+        self.acc = None
         self.program_code = Compiler(self).make_program()
         self.build_options = list(build_options if build_options is not None else PARITY_OPTIONS)
         extra = getattr(args, 'cl_build_options', None)
         if extra:
             self.build_options += extra.split()
-        # path regeneration (main.hip): identical results; no gain while all pixels share their
-        # random numbers, +26..44 % once every pixel draws its own
-        self.regenerate = self.rng_mode == 'philox'
-        self.acc = None
         if device:
             self.connect(device_index)
+
+    @property
+    def regenerate(self):
+        return self._regenerate
+
+    @regenerate.setter
+    def regenerate(self, value):
+        """The two forms of clr_render are two programs: switching regenerates and rebuilds."""
+        if bool(value) == self._regenerate:
+            return
+        self._regenerate = bool(value)
+        self.program_code = Compiler(self).make_program()
+        if self.acc is not None:
+            self._build()
 
     # ------------------------------------------------------------------ scene preparation
     def _group_objects(self):

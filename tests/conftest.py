@@ -36,8 +36,8 @@ def load_scene(name, size=None, **overrides):
     elif name.startswith('scene-mesh'):
         # 'scene-mesh:<n_u>x<n_v>:<layout>:<overlap>', layout 'flat-lanes' = flat, not pooled;
         # overlap 'reference' (default here: the reference's tree) or 'sat'
-        _, grid, layout, overlap = (name.split(':') + ['120x60', 'flat', 'reference'])[:4] if ':' in name \
-            else (name, '120x60', 'flat', 'reference')
+        parts = name.split(':')[1:]
+        grid, layout, overlap = parts + ['120x60', 'flat', 'reference'][len(parts):]
         n_u, n_v = (int(v) for v in grid.split('x'))
         make = runpy.run_path(os.path.join(SCENE_DIR, 'scene-mesh.py'), run_name='lib')['make_scene']
         if layout == 'flat-lanes':
