@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument('--mesh-overlap', choices=['sat', 'reference'], default='sat',
                     help="scene-mesh: rule that files faces under octree leaves (same hits either way): "
                          "'sat' triangle against box, 'reference' the reference's bounding-sphere rule")
+    ap.add_argument('--marchers', default=None,
+                    help='scene-marchers: comma-separated names of the ray-marched objects to keep (development)')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--regenerate', type=int, default=None, help='path regeneration 1/0 (default: on with --rng philox)')
     ap.add_argument('--rng', choices=['tape', 'philox'], default='tape',
@@ -64,6 +66,8 @@ def parse_args():
                          "before the run), 'none' or a number")
     ap.add_argument('--split-passes', type=int, default=None,
                     help='1/0: pass-split program (several lanes per pixel) on/off; default: on for small frames')
+    ap.add_argument('--pass-groups', type=int, default=None,
+                    help='pass-split program: lanes per pixel at least (default: 4 for mesh scenes, else 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
@@ -155,6 +159,8 @@ def main():
             n_u, n_v = (int(v) for v in args.mesh_grid.lower().split('x'))
             scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout,
                                                                        overlap=args.mesh_overlap)
+        elif args.scene == 'scene-marchers' and args.marchers is not None:
+            scene = runpy.run_path(path, run_name='lib')['make_scene'](only=args.marchers.split(','))
         else:
             scene = runpy.run_path(path)['scene']
         scene.image.size = (width, height)
@@ -172,6 +178,8 @@ def main():
                  bake_parameters=None if args.bake is None else bool(args.bake),
                  split_passes=None if args.split_passes is None else bool(args.split_passes),
                  **shard.renderer_arguments())
+    if args.pass_groups:
+        r.min_pass_groups = args.pass_groups
     shard.configure(r)                          # per-pixel random numbers are keyed by the GLOBAL pass index
     if args.regenerate is not None:
         r.regenerate = bool(args.regenerate)
@@ -179,7 +187,7 @@ def main():
         r.tune_occupancy()                      # part of the program build, outside the timed region
         if rank == 0:
             print('occupancy tuning (ms per hint):', {str(k): round(v, 3) for k, v in r.occupancy_timings.items()},
-                  'scratch bytes per lane:', r.occupancy_scratch, file=sys.stderr)
+                  'spilled vector registers:', r.occupancy_scratch, file=sys.stderr)
     frame = torch.zeros((shard.frame_rows, 4), dtype=torch.float32, device='cuda')
     img = shard.my_rows(frame)[:r.n_pixels]
     r.use_image_buffer(img.data_ptr())
@@ -241,6 +249,10 @@ def main():
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'speculative_exact_arithmetic': bool(r.speculate),
                    'occupancy_hint': r.min_waves_per_simd,
+                   'kernel_registers': {key.lstrip('.'): value for key, value in getattr(r, 'kernel_metadata', {}).items()
+                                        if key in ('.vgpr_count', '.sgpr_count', '.vgpr_spill_count',
+                                                   '.sgpr_spill_count', '.private_segment_fixed_size',
+                                                   '.group_segment_fixed_size')},
                    'pass_groups': r._split_args(args.passes_per_step)['pass_groups'] if r.split_passes else 1,
                    'parallelism': ('%s x%d, one all-reduce' % ('tile-partitioned' if tiles else 'pass-striped', world))
                                   if world > 1 else 'single GPU'},

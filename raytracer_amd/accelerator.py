@@ -324,6 +324,8 @@ class Accelerator:
         from . import program_cache
         arch = self.device_info()['arch'].split(':')[0]
         binary, self.last_build = program_cache.get_binary(prog_code, list(options), arch)
+        # what the compiler says about the kernels (registers, spills, scratch), per program handle
+        self.last_metadata = program_cache.kernel_metadata(binary)
         prog = ctypes.c_void_p()
         _check(self.lib.clr_program_load(self.ctx, binary, len(binary), ctypes.byref(prog)))
         self.prog = prog

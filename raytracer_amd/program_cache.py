@@ -145,3 +145,83 @@ def get_binary(source, options, arch):
         except OSError:
             pass
     return binary, how
+
+
+# ---------------------------------------------------------------- code object metadata
+def _msgpack(buf, pos=0):
+    """Minimal MessagePack reader (maps, arrays, strings, integers, booleans, nil, floats):
+    returns (value, next position).  The AMDGPU code object metadata uses nothing else."""
+    import struct
+    b = buf[pos]
+    pos += 1
+    if b <= 0x7f:
+        return b, pos
+    if 0x80 <= b <= 0x8f or b in (0xde, 0xdf):
+        n = b & 0x0f if b <= 0x8f else int.from_bytes(buf[pos:pos + (2 if b == 0xde else 4)], 'big')
+        pos += 0 if b <= 0x8f else (2 if b == 0xde else 4)
+        out = {}
+        for _ in range(n):
+            key, pos = _msgpack(buf, pos)
+            out[key], pos = _msgpack(buf, pos)
+        return out, pos
+    if 0x90 <= b <= 0x9f or b in (0xdc, 0xdd):
+        n = b & 0x0f if b <= 0x9f else int.from_bytes(buf[pos:pos + (2 if b == 0xdc else 4)], 'big')
+        pos += 0 if b <= 0x9f else (2 if b == 0xdc else 4)
+        out = []
+        for _ in range(n):
+            item, pos = _msgpack(buf, pos)
+            out.append(item)
+        return out, pos
+    if 0xa0 <= b <= 0xbf or b in (0xd9, 0xda, 0xdb, 0xc4, 0xc5, 0xc6):
+        width = {0xd9: 1, 0xda: 2, 0xdb: 4, 0xc4: 1, 0xc5: 2, 0xc6: 4}.get(b, 0)
+        n = b & 0x1f if not width else int.from_bytes(buf[pos:pos + width], 'big')
+        pos += width
+        raw = bytes(buf[pos:pos + n])
+        return (raw if b in (0xc4, 0xc5, 0xc6) else raw.decode('utf-8', 'replace')), pos + n
+    if b == 0xc0:
+        return None, pos
+    if b in (0xc2, 0xc3):
+        return b == 0xc3, pos
+    if b in (0xcc, 0xcd, 0xce, 0xcf):
+        width = 1 << (b - 0xcc)
+        return int.from_bytes(buf[pos:pos + width], 'big'), pos + width
+    if b in (0xd0, 0xd1, 0xd2, 0xd3):
+        width = 1 << (b - 0xd0)
+        return int.from_bytes(buf[pos:pos + width], 'big', signed=True), pos + width
+    if b == 0xca:
+        return struct.unpack('>f', buf[pos:pos + 4])[0], pos + 4
+    if b == 0xcb:
+        return struct.unpack('>d', buf[pos:pos + 8])[0], pos + 8
+    if b >= 0xe0:
+        return b - 0x100, pos
+    raise ValueError('unsupported MessagePack type 0x%02x' % b)
+
+
+def kernel_metadata(binary):
+    """{kernel name: metadata map} from the NT_AMDGPU_METADATA note of a gfx9 code object (ELF64,
+    possibly inside a clang offload bundle): registers, spills, scratch and LDS of every kernel,
+    as the compiler states them (`.vgpr_count`, `.vgpr_spill_count`, `.sgpr_spill_count`,
+    `.private_segment_fixed_size`, `.group_segment_fixed_size`, ...)."""
+    import struct
+    start = binary.find(b'\x7fELF')
+    if start < 0:
+        return {}
+    elf = memoryview(binary)[start:]
+    shoff, = struct.unpack_from('<Q', elf, 0x28)
+    shentsize, shnum = struct.unpack_from('<HH', elf, 0x3a)
+    for i in range(shnum):
+        sh = shoff + i * shentsize
+        sh_type, = struct.unpack_from('<I', elf, sh + 4)
+        offset, size = struct.unpack_from('<QQ', elf, sh + 0x18)
+        if sh_type != 7:                       # SHT_NOTE
+            continue
+        pos, end = offset, offset + size
+        while pos + 12 <= end:
+            namesz, descsz, ntype = struct.unpack_from('<III', elf, pos)
+            name_at = pos + 12
+            desc_at = name_at + (namesz + 3) // 4 * 4
+            if ntype == 32 and bytes(elf[name_at:name_at + 6]) == b'AMDGPU':
+                meta, _ = _msgpack(elf[desc_at:desc_at + descsz])
+                return {k['.name']: k for k in meta.get('amdhsa.kernels', [])}
+            pos = desc_at + (descsz + 3) // 4 * 4
+    return {}

@@ -59,7 +59,7 @@ SPILL_MARGIN = 0.03
 
 
 def pick_occupancy_hint(timings, scratch):
-    """The fastest candidate among those with the least scratch per lane, unless one that spills
+    """The fastest candidate among those that spill the fewest registers, unless one that spills
     more beats it by more than SPILL_MARGIN."""
     least = min(scratch.values())
     lean = min((h for h in timings if scratch[h] == least), key=timings.get)
@@ -126,6 +126,8 @@ class Renderer:
         if split_passes is None:
             split_passes = 2 * self.n_pixels <= 3 * FULL_GPU_LANES or self.has_mesh
         self.split_passes = bool(split_passes)
+        # lanes per pixel a pass-split launch uses at least (more on small frames, pass_groups_for)
+        self.min_pass_groups = 4 if self.has_mesh else 1
         self._pass_log = None
         # optional occupancy hint for the render kernel (second __launch_bounds__ argument)
         self.min_waves_per_simd = min_waves_per_simd
@@ -440,13 +442,14 @@ class Renderer:
         # all candidates stay loaded and are timed in interleaved rounds, so that clock and
         # thermal drift hits them alike (differences of 3-5 % decide here)
         previous = self.acc.prog
-        built = {}
+        built, meta = {}, {}
         for hint in candidates:
             self.min_waves_per_simd = hint
             code = Compiler(self).make_program()
             self.program_code = code
             self._build(keep_previous=True)
             built[hint] = (self.acc.prog, code)
+            meta[hint] = self.acc.last_metadata.get('clr_render', {})
             self.render_tape(tape)                                       # warm-up
         self.acc.drop_program(previous)
         samples = {hint: [] for hint in candidates}
@@ -455,13 +458,14 @@ class Renderer:
                 self.acc.use_program(built[hint][0])
                 samples[hint].append(self.render_tape(tape)[0])
         timings = {hint: float(np.median(v)) for hint, v in samples.items()}
-        # scratch bytes per lane of each build: a build that needs more than the leanest one
-        # spills registers (inside the segment loop, as measured on scene-dev with hint 7: 7 x the
-        # algorithmic HBM writes), which hurts any neighbour on the GPU and is bought by noise-level
-        # gains; such a build has to win by SPILL_MARGIN to be chosen
-        scratch = {hint: self.acc.kernel_info('clr_render', prog=built[hint][0])['scratch_bytes'] for hint in candidates}
+        # vector registers each build spills to scratch memory (code object metadata): a build that
+        # spills more than the leanest one moves registers through HBM inside the segment loop (as
+        # measured on scene-dev with hint 7: 7 x the algorithmic HBM writes), which hurts any
+        # neighbour on the GPU and is bought by noise-level gains; such a build has to win by
+        # SPILL_MARGIN to be chosen
+        scratch = {hint: int(meta[hint].get('.vgpr_spill_count', 0)) for hint in candidates}
         if verbose:
-            print('occupancy hints, median ms:', timings, 'scratch bytes per lane:', scratch)
+            print('occupancy hints, median ms:', timings, 'spilled vector registers:', scratch)
         best = pick_occupancy_hint(timings, scratch)
         self.min_waves_per_simd = best
         self.prog, self.program_code = built[best]
@@ -473,6 +477,7 @@ class Renderer:
         self.dev_pass_tape, self.dev_bounce_tape, self.dev_rows, self._tape_capacity, self._resident_passes = saved_tape
         self.occupancy_timings = timings
         self.occupancy_scratch = scratch
+        self.kernel_metadata = meta[best]
         return best
 
     def _upload_tape(self, tape):
@@ -540,7 +545,7 @@ class Renderer:
         """The pass-split fields of clr_render_args (empty for a one-lane-per-pixel program)."""
         if not self.split_passes:
             return {}
-        groups = 1 if debug else pass_groups_for(self.n_pixels, n_passes, 4 if self.has_mesh else 1)
+        groups = 1 if debug else pass_groups_for(self.n_pixels, n_passes, self.min_pass_groups)
         if static_log:
             return dict(pass_log=None, pass_groups=groups)
         floats = 1 + 6 * self.scene.max_bounces

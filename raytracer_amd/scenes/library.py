@@ -297,20 +297,23 @@ ROUNDED_BOX_TORUS = (
     "dist = fmin(box, torus)")
 
 
-def scene_marchers():
+def scene_marchers(only=None):
+    """only: names of the ray-marched objects to keep (development: cost of each one alone)."""
     s = BoxScene()
     s.get_object('light').bidirectional_light = True
     R = z = MARCHER_RADIUS
-    s.add_object(ImplicitSurface('x**4 - 5*x**2 + y**4 - 5*y**2 + z**4 - 5*z**2 + 11.8',
-                                 (-1.2, 0.8, z), R * 0.5, 4), 'mirror', 'implicit')
-    s.add_object(DistanceField("dist = sqrt(x*x + y*y + z*z) - %g" % R, center=(0.0, 1.6, z)),
-                 'glass', 'sdf-sphere')
-    s.add_object(DistanceField(ROUNDED_BOX_TORUS, center=(1.2, 0.6, z), bndR=0.7),
-                 'white', 'sdf-box-torus')
-    s.add_object(QuaternionJuliaSet(JULIA_C, 4, center=(-0.4, -0.6, z), scale=R), 'white', 'julia-ia')
-    s.add_object(QuaternionJuliaSet2(JULIA_C, 4, center=(0.9, -0.9, z), scale=R), 'wax', 'julia-de')
-    for tracer in (o.tracer for o in s.objects[-5:]):
-        tracer.rotate(axis='z', deg=-30)
+    marchers = [
+        (ImplicitSurface('x**4 - 5*x**2 + y**4 - 5*y**2 + z**4 - 5*z**2 + 11.8',
+                         (-1.2, 0.8, z), R * 0.5, 4), 'mirror', 'implicit'),
+        (DistanceField("dist = sqrt(x*x + y*y + z*z) - %g" % R, center=(0.0, 1.6, z)), 'glass', 'sdf-sphere'),
+        (DistanceField(ROUNDED_BOX_TORUS, center=(1.2, 0.6, z), bndR=0.7), 'white', 'sdf-box-torus'),
+        (QuaternionJuliaSet(JULIA_C, 4, center=(-0.4, -0.6, z), scale=R), 'white', 'julia-ia'),
+        (QuaternionJuliaSet2(JULIA_C, 4, center=(0.9, -0.9, z), scale=R), 'wax', 'julia-de'),
+    ]
+    for tracer, material, name in marchers:
+        if only is None or name in only:
+            tracer.rotate(axis='z', deg=-30)
+            s.add_object(tracer, material, name)
     s.image.size = (3840, 2160)
     s.samples_per_pixel = 16
     s.max_bounces = 4

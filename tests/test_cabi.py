@@ -95,3 +95,17 @@ def test_program_store_and_child_compile(tmp_path, monkeypatch):
     with pytest.raises(Exception) as err:
         program_cache.compile_in_child('this is not HIP', [], 'gfx950')
     assert 'error' in str(err.value).lower()
+
+
+def test_code_object_metadata_is_read_without_a_device():
+    """program_cache.kernel_metadata: registers and spills of each kernel from the code object's
+    NT_AMDGPU_METADATA note (what the occupancy tuner uses to stay away from builds that spill)."""
+    from raytracer_amd import program_cache
+    source = ('extern "C" __global__ void a(float *p) { p[threadIdx.x] *= 2.0f; }\n'
+              'extern "C" __global__ void __launch_bounds__(64) b(float *p, int n) '
+              '{ __shared__ float s[64]; s[threadIdx.x] = p[threadIdx.x]; __syncthreads(); p[threadIdx.x] = s[63 - threadIdx.x] * n; }\n')
+    meta = program_cache.kernel_metadata(program_cache.compile_here(source, ['-O3'], 'gfx950'))
+    assert sorted(meta) == ['a', 'b']
+    assert meta['b']['.group_segment_fixed_size'] == 256 and meta['b']['.max_flat_workgroup_size'] == 64
+    assert meta['a']['.vgpr_spill_count'] == 0 and 0 < meta['a']['.vgpr_count'] <= 16
+    assert program_cache.kernel_metadata(b'not a code object') == {}

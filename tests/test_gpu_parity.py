@@ -385,6 +385,25 @@ def test_device_tone_mapping_matches_host_pipeline(low_norm):
         r.get_display_image(settings)
 
 
+def test_device_tone_mapping_against_the_reference_fixture():
+    """tonemap.hip against what the reference's own Image._to_24bit returned (tests/golden/
+    host-io.npz, made by tools/make_golden.py host-io) for five settings: default, other gamma and
+    brightness, no floor, with earlier sums (--append), both.  The device evaluates the same
+    binary64 pipeline with the scaling folded into one factor: at most one count of difference
+    on at most 1e-4 of the values."""
+    from test_host_api import tonemap_cases
+    from raytracer_amd.accelerator import Accelerator
+    r = Renderer(load_scene('scene-dev', (64, 48)), seed=4)
+    for name, settings, base, sums, want in tonemap_cases():
+        assert sums.shape == r.img_shape + (3,)
+        per_ray = Accelerator.host_vec3_array(sums[r.image_order[:, 0], r.image_order[:, 1]])
+        r.img.set(per_ray)
+        got = r.get_display_image(settings, base=base)
+        assert got.shape == want.shape and got.dtype == np.uint8
+        diff = np.abs(got.astype(int) - want.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4, (name, diff.max(), (diff > 0).mean())
+
+
 def test_box_light_and_two_lights_bit_exact():
     """A Parallelepiped as a second next-event light (the reference has the light
     interface for Sphere only, so this is checked against the oracle and by its effect)."""

@@ -429,3 +429,30 @@ def test_octree_hits_equal_brute_force_under_both_overlap_rules():
         assert np.array_equal(face[on_knot], results[0][1][on_knot])
         assert np.array_equal(t.view(np.uint32), results[0][2].view(np.uint32))
         assert np.array_equal(normal.view(np.uint32), results[0][3].view(np.uint32))
+
+
+def tonemap_cases():
+    """(name, settings, base or None, sums, expected uint8 image) of tests/golden/host-io.npz: what
+    the reference's Image._to_24bit (/root/reference/imgutils.py:60-80) returned."""
+    import os
+    from conftest import GOLDEN_DIR
+    from raytracer_amd.imgutils import ColorEncodingSettings
+    fx = np.load(os.path.join(GOLDEN_DIR, 'host-io.npz'))
+    for name in fx['tonemap_cases']:
+        gamma, brightness, floor, with_base = fx['tonemap_%s_settings' % name]
+        settings = ColorEncodingSettings()
+        settings.gamma, settings.brightness = float(gamma), float(brightness)
+        settings.low_normalization = np.min if floor else None
+        yield (str(name), settings, fx['tonemap_base'] if with_base else None, fx['tonemap_sums'],
+               fx['tonemap_%s_rgb' % name])
+
+
+def test_host_tone_mapping_equals_the_reference():
+    from raytracer_amd.imgutils import Image
+    seen = 0
+    for name, settings, base, sums, want in tonemap_cases():
+        got = Image(data=None if base is None else base.copy(), settings=settings)._to_24bit(sums.astype(np.float64))
+        assert got.dtype == np.uint8 and np.array_equal(got, want), name
+        assert want.std() > 10 and (want == 255).any()
+        seen += 1
+    assert seen == 5

@@ -127,3 +127,29 @@ def test_hostile_headers_and_unseekable_files_fail_cleanly(tmp_path):
         read_mesh(fifo)
     t.join()
     assert 'not a regular file' in str(err.value)
+
+
+@pytest.mark.parametrize('name', ['a.off', 'b.off', 'c.ply'])
+def test_readers_match_what_the_reference_readers_returned(tmp_path, name):
+    """tests/golden/host-io.npz (tools/make_golden.py host-io): generated OFF / zipper files and
+    what the reference's own read_off / read_zipper / remove_duplicate_faces
+    (/root/reference/mesh_formats.py:14-82) returned for them.  The native readers of
+    csrc/mesh_io.cpp and this package's Python readers must return the same arrays."""
+    from conftest import GOLDEN_DIR
+    fx = np.load(os.path.join(GOLDEN_DIR, 'host-io.npz'))
+    key = 'mesh_' + name.replace('.', '_')
+    text = fx[key + '_text'].tobytes().decode('ascii')
+    path = tmp_path / name
+    path.write_text(text)
+    want_vertices, want_faces, want_unique = fx[key + '_vertices'], fx[key + '_faces'], fx[key + '_unique_faces']
+    assert len(want_unique) < len(want_faces)                    # the files do hold repeated faces
+    vertices, triangles = read_mesh(str(path))
+    assert vertices.dtype == np.float64 and np.array_equal(vertices, want_vertices)
+    assert np.array_equal(triangles, want_faces)
+    assert np.array_equal(triangles[unique_faces(triangles)], want_unique)
+    reader = meshes.read_off if name.endswith('.off') else meshes.read_zipper
+    py_vertices, py_faces = reader(io.StringIO(text))
+    assert np.array_equal(np.array([v[:3] for v in py_vertices]), want_vertices)
+    assert [len(v) for v in py_vertices] == list(fx[key + '_vertex_columns'])
+    assert np.array_equal(np.array(py_faces), want_faces)
+    assert np.array_equal(np.array(meshes.remove_duplicate_faces(py_faces)), want_unique)

@@ -437,7 +437,100 @@ def make_fixture(scene_name, size, n_passes, seed):
     return fx
 
 
+def mesh_file_texts(rng):
+    """Generated OFF / zipper files that exercise the reference readers' record rules
+    (mesh_formats.py:14-70): counts on the OFF line or the next one, polygons of 3-6 vertices
+    (fan-triangulated), extra columns after the coordinates, repeated faces, exponent notation."""
+    def vertex_lines(n, extra):
+        lines = []
+        for _ in range(n):
+            xyz = rng.uniform(-2, 2, 3)
+            fields = ['%.9g' % xyz[0], '%r' % float(np.float32(xyz[1])), '%.3e' % xyz[2]]
+            fields += ['%.4f' % v for v in rng.uniform(0, 1, extra)]
+            lines.append(' '.join(fields))
+        return lines
+
+    def face_lines(n_faces, n_vertices, sizes):
+        lines, faces = [], []
+        for i in range(n_faces):
+            if faces and rng.rand() < 0.15:                  # a repeated face, rotated or reversed
+                ids = list(faces[rng.randint(len(faces))])
+                ids = ids[1:] + ids[:1] if rng.rand() < 0.5 else ids[::-1]
+            else:
+                ids = list(rng.choice(n_vertices, size=sizes[rng.randint(len(sizes))], replace=False))
+            faces.append(ids)
+            lines.append(' '.join(str(v) for v in [len(ids)] + ids))
+        return lines
+    texts = {}
+    texts['a.off'] = '\n'.join(['OFF', '40 60 0'] + vertex_lines(40, 0) + face_lines(60, 40, [3, 4, 5, 6])) + '\n'
+    texts['b.off'] = '\n'.join(['OFF 25 30 77'] + vertex_lines(25, 2) + face_lines(30, 25, [3, 3, 4])) + '\n'
+    texts['c.ply'] = '\n'.join(['ply', 'format ascii 1.0', 'comment zipper output', 'element vertex 30',
+                                'property float x', 'property float y', 'property float z',
+                                'property float confidence', 'property float intensity',
+                                'element face 45', 'property list uchar int vertex_indices', 'end_header']
+                               + vertex_lines(30, 2) + face_lines(45, 30, [3, 3, 3, 4])) + '\n'
+    return texts
+
+
+def make_host_io_fixture(seed=5):
+    """Rows f2 / f3 of SURVEY section 8: the reference's own mesh readers and tone mapper run on
+    generated inputs (mesh_formats.read_off / read_zipper / remove_duplicate_faces,
+    imgutils.Image._to_24bit without the flare effect).  The fixture keeps the inputs (file texts
+    written by this script, image sums) and what the reference returned."""
+    import_reference()
+    import io
+    import mesh_formats as ref_mesh
+    import imgutils as ref_img
+    rng = np.random.RandomState(seed)
+    fx = {}
+    for name, text in mesh_file_texts(rng).items():
+        reader = ref_mesh.read_off if name.endswith('.off') else ref_mesh.read_zipper
+        with open(os.devnull, 'w') as sink:            # the readers print progress
+            stdout, sys.stdout = sys.stdout, sink
+            try:
+                vertices, faces = reader(io.StringIO(text))
+            finally:
+                sys.stdout = stdout
+        unique = ref_mesh.remove_duplicate_faces(faces)
+        key = name.replace('.', '_')
+        fx['mesh_%s_text' % key] = np.frombuffer(text.encode('ascii'), dtype=np.uint8)
+        fx['mesh_%s_vertices' % key] = np.array([v[:3] for v in vertices], dtype=np.float64)
+        fx['mesh_%s_vertex_columns' % key] = np.array([len(v) for v in vertices])
+        fx['mesh_%s_faces' % key] = np.array(faces, dtype=np.int32)
+        fx['mesh_%s_unique_faces' % key] = np.array(unique, dtype=np.int32)
+    # tone mapping: sums as a float32 accumulator would hold them, with black, dim, over-exposed
+    # and (for the nan_to_num step) a few NaN pixels
+    height, width = 48, 64
+    sums = rng.gamma(0.7, 30.0, size=(height, width, 3)).astype(np.float32)
+    sums[:4] *= 0.001
+    sums[10:14, 20:30] *= 50.0
+    sums[5, 5] = 0.0
+    base = (rng.gamma(0.7, 12.0, size=(height, width, 3)) + 0.5)
+    fx['tonemap_sums'] = sums
+    fx['tonemap_base'] = base
+    cases = [('default', {}, False), ('gamma16_dim', {'gamma': 1.6, 'brightness': 0.3}, False),
+             ('no_floor', {'low_normalization': None}, False), ('appended', {}, True),
+             ('appended_no_floor', {'low_normalization': None, 'gamma': 2.2}, True)]
+    for name, changes, with_base in cases:
+        settings = ref_img.ColorEncodingSettings()
+        for key, value in changes.items():
+            setattr(settings, key, value)
+        image = ref_img.Image(data=base.copy() if with_base else None, settings=settings)
+        fx['tonemap_%s_rgb' % name] = image._to_24bit(sums.astype(np.float64))
+        fx['tonemap_%s_settings' % name] = np.array([settings.gamma, settings.brightness,
+                                                     0.0 if settings.low_normalization is None else 1.0,
+                                                     1.0 if with_base else 0.0])
+    fx['tonemap_cases'] = np.array([c[0] for c in cases])
+    return fx
+
+
 def main():
+    if sys.argv[1:] == ['host-io']:
+        os.makedirs(OUT, exist_ok=True)
+        path = os.path.join(OUT, 'host-io.npz')
+        np.savez_compressed(path, **make_host_io_fixture())
+        print('host-io ->', path, '%.1f kB' % (os.path.getsize(path) / 1e3))
+        return
     names = sys.argv[1:] or ['scene-dev', 'scene-three-objects', 'scene-test', 'variant-camera', 'variant-media',
                              'spectral-dev', 'spectral-stairs']
     os.makedirs(OUT, exist_ok=True)

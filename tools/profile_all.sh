@@ -16,6 +16,7 @@ for cfg in "$@"; do
         marchers) run prof_marchers --scene scene-marchers --size 3840x2160 --passes-per-step 16 --steps 3 --warmup 1 || exit 1;;
         mesh) run prof_mesh --scene scene-mesh --passes-per-step 16 --steps 3 --warmup 1 || exit 1;;
         test) run prof_test --scene scene-test --size 320x240 --passes-per-step 16 --steps 10 --warmup 2 || exit 1;;
+        marcher:*) run prof_${cfg#marcher:} --scene scene-marchers --size 3840x2160 --passes-per-step 16 --steps 2 --warmup 1 --marchers ${cfg#marcher:} || exit 1;;
         *) echo "unknown configuration $cfg"; exit 1;;
     esac
 done

@@ -49,7 +49,9 @@ def main(tag, key, src=None):
     summary = {
         'kernel': 'clr_render', 'launches': len(rows),
         'avg_ms': sum(durations) / len(durations), 'min_ms': min(durations), 'max_ms': max(durations),
-        'vgpr': int(rows[0]['VGPR_Count']), 'sgpr': int(rows[0]['SGPR_Count']),
+        # rocprofv3's VGPR_Count column is about half the code object's .vgpr_count (which bench.py
+        # reports as config.kernel_registers): e.g. 36-40 here for an 72-80 register kernel
+        'rocprof_vgpr_column': int(rows[0]['VGPR_Count']), 'rocprof_sgpr_column': int(rows[0]['SGPR_Count']),
         'grid': int(rows[0]['Grid_Size_X']), 'workgroup': int(rows[0]['Workgroup_Size_X']),
         'counters_per_launch': counters,
         'hbm_read_bytes_per_launch': fetch, 'hbm_write_bytes_per_launch': write,
