@@ -103,5 +103,42 @@ def spectral_stairs(api, n_steps=12):
     return s
 
 
-VARIANTS = {'variant-camera': variant_camera, 'variant-media': variant_media,
+def bumpy_torus(n_u=60, n_v=40):
+    """(vertices (n_u * n_v, 3), faces (2 n_u n_v, 3)): a torus with a rippled tube, 4800 triangles."""
+    import numpy as np
+    u, v = np.meshgrid(np.linspace(0, 2 * np.pi, n_u, endpoint=False),
+                       np.linspace(0, 2 * np.pi, n_v, endpoint=False), indexing='ij')
+    tube = 0.33 + 0.05 * np.sin(5 * u) * np.cos(3 * v)
+    ring = 1.0 + tube * np.cos(v)
+    vertices = np.stack((ring * np.cos(u), ring * np.sin(u), tube * np.sin(v) + 0.08 * np.sin(2 * u)), axis=-1)
+    i, j = np.meshgrid(np.arange(n_u), np.arange(n_v), indexing='ij')
+    a = (i * n_v + j).ravel()
+    b = (((i + 1) % n_u) * n_v + j).ravel()
+    c = (((i + 1) % n_u) * n_v + (j + 1) % n_v).ravel()
+    d = (i * n_v + (j + 1) % n_v).ravel()
+    faces = np.concatenate((np.stack((a, b, c), 1), np.stack((a, c, d), 1)))
+    return vertices.reshape(-1, 3), faces.astype(np.int32)
+
+
+def variant_mesh(api):
+    """A smooth-shaded 4800-triangle mesh inside an Octree (depth 4) built by the scene API's own
+    builder, tilted, glass next to it: pins the octree stream at a size where the tree is deep,
+    the smooth normals (vertex normals interpolated by barycentric weights) and everything a path
+    does after hitting a mesh.  (The reference generates the smooth-normal code for every Octree,
+    which is only right for a smooth mesh like this one - tests/test_golden.py, flat_octree_ids.)"""
+    s = api.BoxScene()
+    s.get_object('light').bidirectional_light = True
+    vertices, faces = bumpy_torus()
+    mesh = api.TriangleMesh(vertices, faces, center=(0.1, 0.4, 0.9), scale=0.9, auto_scale=True,
+                            shading='smooth', auto_smooth_normals=True)
+    mesh.rotate(axis='x', deg=35)
+    s.add_object(api.Octree(mesh, max_depth=4, max_faces_per_leaf=6), 'white', 'torus')
+    s.add_object(api.Sphere((-1.0, -0.8, 0.4), 0.4), 'glass')
+    s.max_bounces = 4
+    s.min_bounces = 2
+    s.direct_camera_towards((0, 0.3, 0.7))
+    return s
+
+
+VARIANTS = {'variant-camera': variant_camera, 'variant-mesh': variant_mesh, 'variant-media': variant_media,
             'spectral-dev': spectral_dev, 'spectral-stairs': spectral_stairs}

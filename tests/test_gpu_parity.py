@@ -214,7 +214,7 @@ def test_bad_arguments_are_rejected():
         r.acc.render_passes(RenderArgs(n_pixels=10, n_passes=1))
 
 
-@pytest.mark.parametrize('name', SCENES + ['variant-camera', 'variant-media', 'spectral-dev', 'spectral-stairs'])
+@pytest.mark.parametrize('name', SCENES + ['variant-camera', 'variant-media', 'variant-mesh', 'spectral-dev', 'spectral-stairs'])
 def test_hip_against_reference_golden(name):
     """HIP directly against the fixtures made from the reference's own device code
     (tests/test_golden.py explains the fixtures and the bars)."""
@@ -248,6 +248,28 @@ def test_hip_against_reference_golden(name):
         rmse = np.sqrt(np.mean((got[:, c] - ref[:, c]) ** 2))
         assert rmse <= 1e-4 * max(np.sqrt(np.mean(ref[:, c] ** 2)), 1e-12), (c, rmse)
     assert near(got, ref, 1e-4).all()
+
+
+def test_scene_test_at_its_real_size_against_reference_golden():
+    """BASELINE configuration C1 at its stated size (320 x 240, 16 passes) on the device, against
+    the compact fixture the reference's own code produced (tests/test_golden.py)."""
+    import os
+    from conftest import GOLDEN_DIR
+    from test_golden import compact_fixture_checks, compare_compact_image
+    fx = np.load(os.path.join(GOLDEN_DIR, 'scene-test-320x240.npz'))
+    r = Renderer(load_scene('scene-test', (320, 240), samples_per_pixel=16), seed=int(fx['seed']))
+    assert r.split_passes                                   # the small-frame program form
+
+    def render_pass(tape):
+        return r.render_tape(tape, debug=True)[1]
+    tainted = compact_fixture_checks('scene-test', fx, r, r.first_hit, render_pass)
+    compare_compact_image(r.img.get(), fx, tainted)
+    # and all 16 passes in one pass-split launch give the same sums as pass by pass
+    from test_golden import rows_of
+    pass_by_pass = r.img.get()
+    r.img.fill(0)
+    r.render_tape((fx['pass_tape'], fx['bounce_tape'], rows_of(fx)))
+    assert np.array_equal(bits(r.img.get()), bits(pass_by_pass))
 
 
 def test_empty_scene_renders_black():

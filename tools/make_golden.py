@@ -289,7 +289,15 @@ def import_reference():
     return ref_renderer
 
 
-def make_fixture(scene_name, size, n_passes, seed):
+SNAPSHOT_PASS = 0      # the pass whose per-segment ray state is recorded (development: set another)
+
+COMPACT_KEYS = ('size', 'seed', 'n_passes', 'object_names', 'patch', 'pass_tape', 'bounce_tape', 'material_rows',
+                'img', 'n_segments', 'seg0_pixel', 'seg0_whichobject', 'seg0_which_subobject', 'seg0_isec_dist')
+
+
+def make_fixture(scene_name, size, n_passes, seed, compact=False):
+    """compact: for a configuration's real size - keep the random numbers, the first hits of pass 0
+    and the image sums only (the small fixture of the same scene pins everything else)."""
     ref_renderer = import_reference()
     np.random.seed(seed)
     for mod in [m for m in sys.modules if m == scene_name]:
@@ -303,7 +311,8 @@ def make_fixture(scene_name, size, n_passes, seed):
         api = _types.SimpleNamespace(BoxScene=RefBoxScene, DefaultScene=RefDefaultScene,
                                      SpectrumShader=ref_shader.SpectrumShader,
                                      Affine=ref_transformations.Affine, Cube=ref_objects.Cube,
-                                     Sphere=ref_objects.Sphere,
+                                     Sphere=ref_objects.Sphere, TriangleMesh=ref_objects.TriangleMesh,
+                                     Octree=ref_objects.Octree,
                                      Cylinder=ref_objects.Cylinder, HalfSpace=ref_objects.HalfSpace)
         scene = golden_scenes.VARIANTS[scene_name](api)
     else:
@@ -399,7 +408,7 @@ def make_fixture(scene_name, size, n_passes, seed):
         n = r.cur_n_pixels
         pixel_before = np.array(r.ray_state.pixel[:n])
         ok = original(sample_index, path_index, is_last)
-        if state['pass'] == 0:
+        if state['pass'] == SNAPSHOT_PASS:
             rs = r.ray_state
             snap = {'n': n, 'pixel': pixel_before}
             # thread-indexed scratch -> gather as is; ray-indexed state -> index by pixel
@@ -428,12 +437,19 @@ def make_fixture(scene_name, size, n_passes, seed):
     if spectral:
         fx['material_rows'] = material_rows
     fx['img_after_first_pass'] = images[0]
+    if os.environ.get('CLRAY_GOLDEN_ALL_IMAGES'):      # development: image sums after every pass
+        fx['img_per_pass'] = np.array(images)
     fx['img'] = images[-1]
     fx['n_segments'] = np.array(len(snapshots))
     for b, snap in enumerate(snapshots):
         for key, value in snap.items():
             fx['seg%d_%s' % (b, key)] = np.asarray(value)
     fx['program_kernels'] = np.array(sorted(acc.kernels))
+    if compact:
+        fx = {key: value for key, value in fx.items() if key in COMPACT_KEYS}
+        fx['img'] = fx['img'][:, :3].copy()
+        for key in ('seg0_pixel', 'seg0_whichobject', 'seg0_which_subobject'):
+            fx[key] = fx[key].astype(np.int32)
     return fx
 
 
@@ -535,9 +551,14 @@ def main():
                              'spectral-dev', 'spectral-stairs']
     os.makedirs(OUT, exist_ok=True)
     for name in names:
-        size = (64, 48) if name != 'scene-test' else (64, 48)
-        fx = make_fixture(name, size, n_passes=3, seed=11)
-        path = os.path.join(OUT, name + '.npz')
+        if '@' in name:                 # e.g. scene-test@320x240x16: a configuration's real size, compact
+            name, shape = name.split('@')
+            width, height, n_passes = (int(v) for v in shape.split('x'))
+            fx = make_fixture(name, (width, height), n_passes=n_passes, seed=11, compact=True)
+            path = os.path.join(OUT, '%s-%dx%d.npz' % (name, width, height))
+        else:
+            fx = make_fixture(name, (64, 48), n_passes=3, seed=11)
+            path = os.path.join(OUT, name + '.npz')
         np.savez_compressed(path, **fx)
         print(name, '->', path, '%.1f kB' % (os.path.getsize(path) / 1e3),
               'segments recorded:', int(fx['n_segments']))
