@@ -162,6 +162,25 @@ int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape,
                   const void *vector_data, const void *integer_data, int n_pixels,
                   void *out_ids, void *out_t, void *out_normal, void *stream);
 
+/* ---- the exchange step of a multi-GPU render for a host that drives several GPUs from ONE
+ * process (one clr_ctx per GPU), over RCCL / xGMI.  No counterpart in the reference, which asserts
+ * a single device (accelerator.py:24-25); the path shards because the image is a sum over passes
+ * (renderer.py:24-28).  A communicator spans the devices of `n` contexts (at most one per GPU).
+ * clr_allreduce_sum_f32 sums `count` floats in place across buffers[i] (device memory of
+ * ctxs[i]'s GPU): the per-GPU accumulators of a pass-striped render.  clr_allgather_f32
+ * concatenates count_per_rank floats of send[i] into every recv[i] (n x count_per_rank floats):
+ * the disjoint tiles of a tile-partitioned render.  streams: one hipStream_t per rank or NULL
+ * for the default streams; the calls enqueue and return (clr_sync to wait).  RCCL is loaded on
+ * the first call (dlopen); hosts with one process per GPU use torch.distributed instead
+ * (raytracer_amd/multi_gpu.py). */
+typedef struct clr_comm clr_comm;
+int clr_comm_create(clr_ctx *const *ctxs, int n, clr_comm **out);
+int clr_comm_destroy(clr_comm *comm);
+int clr_comm_size(const clr_comm *comm, int *n);
+int clr_allreduce_sum_f32(clr_comm *comm, void *const *buffers, size_t count, void *const *streams);
+int clr_allgather_f32(clr_comm *comm, const void *const *send, void *const *recv, size_t count_per_rank,
+                      void *const *streams);
+
 /* ---- host-side octree builder: replaces Octree.build + get_data (objects/octree.py:69-156)
  * for meshes the reference's dense numpy construction cannot handle.  No device needed.
  * vertices: n_vertices x 3 floats, faces: n_faces x 3 ints. */

@@ -98,6 +98,11 @@ def load_library():
         'clr_render_passes': (ci, [vp, P(RenderArgs), vp, P(ctypes.c_float)]),
         'clr_render_passes_static_log': (ci, [vp, P(RenderArgs), vp, P(ctypes.c_float)]),
         'clr_first_hit': (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+        'clr_comm_create': (ci, [P(vp), ci, P(vp)]),
+        'clr_comm_destroy': (ci, [vp]),
+        'clr_comm_size': (ci, [vp, P(ci)]),
+        'clr_allreduce_sum_f32': (ci, [vp, P(vp), ctypes.c_size_t, P(vp)]),
+        'clr_allgather_f32': (ci, [vp, P(vp), P(vp), ctypes.c_size_t, P(vp)]),
         'clr_octree_build': (ci, [vp, ci, vp, ci, ci, ci, P(vp)]),
         'clr_octree_build_rule': (ci, [vp, ci, vp, ci, ci, ci, ci, P(vp)]),
         'clr_octree_info': (ci, [vp, P(OctreeInfo)]),
@@ -263,6 +268,48 @@ class DeviceArray:
         row = self.nbytes // max(self.shape[0], 1)
         return DeviceArray(self.acc, (max(stop - start, 0),) + self.shape[1:], self.dtype,
                            ptr=self.ptr + start * row, owner=self)
+
+
+class Communicator:
+    """RCCL communicator over the GPUs of several Accelerators of THIS process (C ABI clr_comm_*):
+    the exchange step for a host that drives all GPUs from one process."""
+
+    def __init__(self, accelerators):
+        self.lib = load_library()
+        self.accelerators = list(accelerators)
+        ctxs = (ctypes.c_void_p * len(self.accelerators))(*[a.ctx for a in self.accelerators])
+        self.comm = ctypes.c_void_p()
+        _check(self.lib.clr_comm_create(ctxs, len(self.accelerators), ctypes.byref(self.comm)))
+
+    def size(self):
+        n = ctypes.c_int(0)
+        _check(self.lib.clr_comm_size(self.comm, ctypes.byref(n)))
+        return n.value
+
+    def allreduce_sum(self, arrays):
+        """In-place sum of equally shaped float32 DeviceArrays, one per GPU."""
+        assert len(arrays) == len(self.accelerators) and all(a.dtype == np.float32 for a in arrays)
+        count = arrays[0].nbytes // 4
+        assert all(a.nbytes == arrays[0].nbytes for a in arrays)
+        ptrs = (ctypes.c_void_p * len(arrays))(*[a.ptr for a in arrays])
+        _check(self.lib.clr_allreduce_sum_f32(self.comm, ptrs, count, None))
+        for acc in self.accelerators:
+            acc.finish()
+
+    def allgather(self, send, recv):
+        """recv[i] (n x the size of a send array) = send[0] | send[1] | ... on every GPU."""
+        count = send[0].nbytes // 4
+        assert all(a.nbytes == send[0].nbytes for a in send) and all(a.nbytes == count * 4 * len(send) for a in recv)
+        s = (ctypes.c_void_p * len(send))(*[a.ptr for a in send])
+        r = (ctypes.c_void_p * len(recv))(*[a.ptr for a in recv])
+        _check(self.lib.clr_allgather_f32(self.comm, s, r, count, None))
+        for acc in self.accelerators:
+            acc.finish()
+
+    def close(self):
+        if self.comm:
+            self.lib.clr_comm_destroy(self.comm)
+            self.comm = None
 
 
 class Accelerator:

@@ -122,6 +122,7 @@ int launch(clr_ctx *ctx, hipFunction_t fn, const unsigned grid[3], const unsigne
 
 // lets the other translation units of the library report through clr_last_error
 extern "C" __attribute__((visibility("hidden"))) void clr_set_error(const char *text) { g_error = text; }
+extern "C" __attribute__((visibility("hidden"))) int clr_ctx_device(const clr_ctx *ctx) { return ctx->device; }
 
 extern "C" {
 

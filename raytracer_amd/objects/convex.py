@@ -126,6 +126,126 @@ class FixedConvexIntersection(UniqueConvexIntersection):
         self.unique_tracer_id = ''
 
 
+class PolyhedronLight:
+    """Light interface (surface_area, random_surface_point_and_normal,
+    center_and_min_sampling_distance) for convex bodies bounded by planes only: any pose, also
+    sheared or stretched.  The reference has the interface for Sphere alone
+    (objects/sphere.py:12-25); SURVEY section 8 row f4.  The boundary is found once per call from
+    the half-spaces of the components: vertices = triple plane intersections that satisfy every
+    half-space, faces = their convex polygons, cut into fans of triangles in world coordinates;
+    a point is drawn uniformly by area (triangle by its share, then uniform in the triangle)."""
+
+    def _half_spaces(self):
+        """[(n, d)]: the body is {x : n.x <= d for all} in tracer coordinates."""
+        planes = []
+        for c in self.components:
+            n = numpy.ravel(numpy.asarray(c.normal, dtype=float))
+            offset = float(numpy.dot(numpy.ravel(numpy.asarray(c.position, dtype=float)), n))
+            if isinstance(c, LayerComponent):
+                planes += [(n, offset + c.h), (-n, -offset)]
+            elif isinstance(c, HalfSpaceComponent):
+                planes.append((n, offset + c.h))
+            else:
+                raise RuntimeError("light interface: %s is not bounded by planes" % type(c).__name__)
+        return planes
+
+    def _world_triangles(self):
+        """[(a, b, c, outward unit normal, area)] in world coordinates."""
+        import itertools
+        planes = self._half_spaces()
+        normals = numpy.array([n for n, _ in planes])
+        heights = numpy.array([d for _, d in planes])
+        scale = max(1.0, numpy.abs(heights).max())
+        vertices = []
+        for i, j, k in itertools.combinations(range(len(planes)), 3):
+            m = normals[[i, j, k]]
+            if abs(numpy.linalg.det(m)) < 1e-12:
+                continue
+            x = numpy.linalg.solve(m, heights[[i, j, k]])
+            if (normals.dot(x) <= heights + 1e-9 * scale).all() and \
+                    not any(numpy.linalg.norm(x - v) < 1e-9 * scale for v in vertices):
+                vertices.append(x)
+        if len(vertices) < 4:
+            raise RuntimeError("light interface: the half-spaces do not bound a body")
+        vertices = numpy.array(vertices)
+        to_world = self.global_to_tracer_coordinate_transform()
+        world = vertices.dot(numpy.asarray(to_world.linear, dtype=float).T) + \
+            numpy.ravel(numpy.asarray(to_world.translation, dtype=float))
+        centre = world.mean(axis=0)
+        triangles = []
+        for n, d in planes:
+            on_face = numpy.flatnonzero(numpy.abs(vertices.dot(n) - d) < 1e-7 * scale)
+            if len(on_face) < 3:
+                continue
+            corners = world[on_face]
+            middle = corners.mean(axis=0)
+            normal = None
+            for a, b in itertools.combinations(range(len(corners)), 2):
+                normal = numpy.cross(corners[a] - middle, corners[b] - middle)
+                if numpy.linalg.norm(normal) > 1e-12:
+                    break
+            normal = normal / numpy.linalg.norm(normal)
+            if numpy.dot(middle - centre, normal) < 0:
+                normal = -normal
+            u = corners[0] - middle
+            u = u / numpy.linalg.norm(u)
+            v = numpy.cross(normal, u)
+            order = numpy.argsort(numpy.arctan2((corners - middle).dot(v), (corners - middle).dot(u)))
+            ring = corners[order]
+            for t in range(1, len(ring) - 1):
+                area = 0.5 * numpy.linalg.norm(numpy.cross(ring[t] - ring[0], ring[t + 1] - ring[0]))
+                triangles.append((ring[0], ring[t], ring[t + 1], normal, area))
+        return triangles
+
+    def surface_area(self):
+        return float(sum(t[4] for t in self._world_triangles()))
+
+    def random_surface_point_and_normal(self, rng=numpy.random):
+        triangles = self._world_triangles()
+        pick, a, b = rng.rand(3)
+        cumulative = numpy.cumsum([t[4] for t in triangles])
+        index = min(int(numpy.searchsorted(cumulative, pick * cumulative[-1], side='right')), len(triangles) - 1)
+        p0, p1, p2, normal, _ = triangles[index]
+        if a + b > 1.0:                      # fold the unit square onto the triangle
+            a, b = 1.0 - a, 1.0 - b
+        return p0 + a * (p1 - p0) + b * (p2 - p0), normal
+
+    def center_and_min_sampling_distance(self):
+        corners = numpy.array([p for t in self._world_triangles() for p in t[:3]])
+        centre = 0.5 * (corners.min(axis=0) + corners.max(axis=0))
+        return centre, 2.0 * float(numpy.linalg.norm(corners - centre, axis=1).max())
+
+
+class RoundLight:
+    """Light interface shared by Cylinder and Cone: discs and a lateral surface of revolution
+    about the local z axis, posed by rotation and translation only (a stretched or sheared pose
+    would make uniform sampling by area a different problem; refused like a scaled Sphere light)."""
+
+    def _check_no_distortion(self):
+        if not self.coordinates.is_orthogonal():
+            raise RuntimeError("illegal operation for a stretched or sheared %s" % type(self).__name__)
+
+    def _frame(self):
+        """World position of the local origin and the unit vectors of the local x, y, z axes."""
+        self._check_no_distortion()
+        rotation = numpy.asarray(self.coordinates.linear, dtype=float).dot(
+            numpy.asarray(rotation_aligning_vectors((0, 0, 1), self.axis), dtype=float))
+        return numpy.ravel(numpy.asarray(self.coordinates.translation, dtype=float)), rotation[:, 0], rotation[:, 1], rotation[:, 2]
+
+    def _draw(self, parts, rng):
+        """parts: [(area, sampler(u, v) -> (point, normal))]; one part by area, then a point on it."""
+        pick, u, v = rng.rand(3)
+        cumulative = numpy.cumsum([p[0] for p in parts])
+        index = min(int(numpy.searchsorted(cumulative, pick * cumulative[-1], side='right')), len(parts) - 1)
+        return parts[index][1](u, v)
+
+    def surface_area(self):
+        return float(sum(p[0] for p in self._parts()))
+
+    def random_surface_point_and_normal(self, rng=numpy.random):
+        return self._draw(self._parts(), rng)
+
+
 # ---------------------------------------------------------------- components
 
 class HalfSpaceComponent(ConvexIntersection.Component):
@@ -209,8 +329,28 @@ class ZConeComponent(ConeComponent):
 
 # ---------------------------------------------------------------- composed shapes
 
-class Cylinder(FixedConvexIntersection):
+class Cylinder(RoundLight, FixedConvexIntersection):
     """Unit z-slab ∩ unit z-cylinder, posed by rotation(axis) ∘ scale(R, R, height)."""
+
+    def _parts(self):
+        origin, ex, ey, ez = self._frame()
+        R, h = float(self.R), float(self.height)
+
+        def disc(z, outward):
+            def sample(u, v):
+                rho, phi = R * math.sqrt(u), 2.0 * math.pi * v
+                return origin + z * ez + rho * (math.cos(phi) * ex + math.sin(phi) * ey), outward
+            return sample
+
+        def side(u, v):
+            phi = 2.0 * math.pi * v
+            radial = math.cos(phi) * ex + math.sin(phi) * ey
+            return origin + u * h * ez + R * radial, radial
+        return [(math.pi * R * R, disc(0.0, -ez)), (math.pi * R * R, disc(h, ez)), (2.0 * math.pi * R * h, side)]
+
+    def center_and_min_sampling_distance(self):
+        origin, ex, ey, ez = self._frame()
+        return origin + 0.5 * self.height * ez, 2.0 * math.hypot(self.R, 0.5 * self.height)
 
     def __init__(self, bottom_center, axis, height, R):
         self.axis = axis
@@ -224,8 +364,29 @@ class Cylinder(FixedConvexIntersection):
         return rotation(Affine(scaling=(self.R, self.R, self.height)))
 
 
-class Cone(FixedConvexIntersection):
+class Cone(RoundLight, FixedConvexIntersection):
     """{z <= 1} ∩ unit z-cone with its tip at the origin, posed like Cylinder."""
+
+    def _parts(self):
+        tip, ex, ey, ez = self._frame()
+        R, h = float(self.R), float(self.height)
+        slant = math.hypot(R, h)
+
+        def base(u, v):
+            rho, phi = R * math.sqrt(u), 2.0 * math.pi * v
+            return tip + h * ez + rho * (math.cos(phi) * ex + math.sin(phi) * ey), ez
+
+        def side(u, v):
+            # area grows linearly with the distance from the tip: that distance is slant * sqrt(u)
+            f, phi = math.sqrt(u), 2.0 * math.pi * v
+            radial = math.cos(phi) * ex + math.sin(phi) * ey
+            return tip + f * (h * ez + R * radial), (h * radial - R * ez) / slant
+        return [(math.pi * R * R, base), (math.pi * R * slant, side)]
+
+    def center_and_min_sampling_distance(self):
+        tip, ex, ey, ez = self._frame()
+        centre = tip + 0.5 * self.height * ez
+        return centre, 2.0 * max(0.5 * self.height, math.hypot(self.R, 0.5 * self.height))
 
     def __init__(self, tip, axis, height, R):
         self.axis = axis
@@ -294,7 +455,7 @@ class Parallelepiped(ConvexIntersection):
         return corner + edges.sum(axis=1) / 2.0, 2.0 * half_diagonal
 
 
-class HyperplaneRepresentation(FixedConvexIntersection):
+class HyperplaneRepresentation(PolyhedronLight, FixedConvexIntersection):
     """Polyhedron given by outward plane vectors p (plane at distance |p| along p)."""
 
     def __init__(self, center, planes, R):
@@ -303,7 +464,7 @@ class HyperplaneRepresentation(FixedConvexIntersection):
         self.linear_transform(scaling=R)
 
 
-class SymmetricDualPolyhedron(FixedConvexIntersection):
+class SymmetricDualPolyhedron(PolyhedronLight, FixedConvexIntersection):
     """Dual of the point-symmetric vertex set {±v}: one slab per listed vertex."""
 
     def __init__(self, center, vertices, R):

@@ -484,11 +484,14 @@ class Renderer:
         passes, bounces, rows = tape
         acc = self.acc
         n = passes.shape[0]
-        if n > self._tape_capacity:
+        if n > self._tape_capacity or (bounces is not None and getattr(self, 'dev_bounce_tape', None) is None) \
+                or (rows is not None and self.dev_rows is None):
+            n = max(n, self._tape_capacity)
             self.dev_pass_tape = acc.new_array((n,) + passes.shape[1:], np.float32)
             self.dev_bounce_tape = acc.new_array((n,) + bounces.shape[1:], np.float32) if bounces is not None else None
             self.dev_rows = (acc.new_array((n, rows.shape[1]), np.float32) if rows is not None else None)
             self._tape_capacity = n
+            n = passes.shape[0]
         self.dev_pass_tape[:n].set(passes)
         if bounces is not None:
             self.dev_bounce_tape[:n].set(bounces)

@@ -456,3 +456,92 @@ def test_host_tone_mapping_equals_the_reference():
         assert want.std() > 10 and (want == 255).any()
         seen += 1
     assert seen == 5
+
+
+def _on_surface(tracer, point, normal, tol=1e-9):
+    """A world point lies on the boundary of a plane-bounded convex body, and `normal` is the
+    outward unit normal of the face it lies on."""
+    to_world = tracer.global_to_tracer_coordinate_transform()
+    local = np.linalg.solve(np.asarray(to_world.linear, float), point - np.ravel(to_world.translation))
+    slack = np.array([d - np.dot(n, local) for n, d in tracer._half_spaces()])
+    if not (slack > -tol).all() or not (np.abs(slack) < 1e-7).any():
+        return False
+    tight = np.argmin(np.abs(slack))
+    face_normal = np.linalg.solve(np.asarray(to_world.linear, float).T, tracer._half_spaces()[tight][0])
+    face_normal /= np.linalg.norm(face_normal)
+    return abs(np.linalg.norm(normal) - 1) < 1e-12 and np.dot(normal, face_normal) > 1 - 1e-9
+
+
+def test_light_interface_of_polyhedra_cylinder_and_cone():
+    """surface_area / random_surface_point_and_normal /
+    center_and_min_sampling_distance beyond the reference's Sphere (objects/sphere.py:12-25).
+    Areas against closed forms, points on the surface with the outward normal of their face,
+    faces drawn in proportion to their area, every point within the stated sampling distance."""
+    rng = np.random.RandomState(3)
+    phi = (1 + 5 ** 0.5) / 2
+    cube = shapes.Cube((1, 2, 3), side=2.0)
+    assert abs(cube.surface_area() - 24.0) < 1e-9
+    # circumradius-style sizes of the regular solids -> edge lengths -> closed-form areas
+    for solid, area_of_edge, faces in ((shapes.Tetrahedron((0, 0, 0), 1.0), lambda a: 3 ** 0.5 * a * a, 4),
+                                       (shapes.Octahedron((0, 0, 0), 1.0), lambda a: 2 * 3 ** 0.5 * a * a, 8),
+                                       (shapes.Icosahedron((0, 0, 0), 1.0), lambda a: 5 * 3 ** 0.5 * a * a, 20),
+                                       (shapes.Dodecahedron((0, 0, 0), 1.0), lambda a: 3 * (25 + 10 * 5 ** 0.5) ** 0.5 * a * a, 12)):
+        triangles = solid._world_triangles()
+        corners = np.unique(np.round(np.array([p for t in triangles for p in t[:3]]), 9), axis=0)
+        edge = min(np.linalg.norm(a - b) for i, a in enumerate(corners) for b in corners[i + 1:])
+        assert abs(solid.surface_area() - area_of_edge(edge)) < 1e-6 * solid.surface_area()
+        assert len({tuple(np.round(t[3], 9)) for t in triangles}) == faces
+    # a sheared, stretched, rotated box: the parallelogram areas of its world-space faces
+    box = shapes.Cube((0.3, -0.2, 0.5), side=1.0)
+    box.linear_transform(linear=[[1.0, 0.4, 0.0], [0.0, 1.5, 0.2], [0.1, 0.0, 0.7]])
+    box.rotate(axis='z', deg=25)
+    # in tracer coordinates the cube is [-1, 1]^3: its world edges are twice the matrix columns
+    m = 2.0 * np.asarray(box.global_to_tracer_coordinate_transform().linear, float)
+    expected = 2 * sum(np.linalg.norm(np.cross(m[:, i], m[:, j])) for i, j in ((0, 1), (1, 2), (0, 2)))
+    assert abs(box.surface_area() - expected) < 1e-9 * expected
+    for solid in (cube, box, shapes.Tetrahedron((1, 0, 0), 0.7), shapes.Dodecahedron((0, 1, 0), 0.5)):
+        centre, reach = solid.center_and_min_sampling_distance()
+        shares = {}
+        for _ in range(400):
+            point, normal = solid.random_surface_point_and_normal(rng)
+            assert _on_surface(solid, point, normal)
+            assert np.linalg.norm(point - centre) <= 0.5 * reach + 1e-9
+            key = tuple(np.round(normal, 6))
+            shares[key] = shares.get(key, 0) + 1
+        by_face = {}
+        for t in solid._world_triangles():
+            by_face[tuple(np.round(t[3], 6))] = by_face.get(tuple(np.round(t[3], 6)), 0.0) + t[4]
+        total = sum(by_face.values())
+        for key, area in by_face.items():
+            assert abs(shares.get(key, 0) / 400.0 - area / total) < 0.09, (key, shares.get(key, 0), area / total)
+    # round bodies: closed-form areas, points on the surface, unit outward normals
+    cyl = shapes.Cylinder((0.5, 0.2, 0.1), (1, 1, 0), 2.0, 0.5)
+    cone = shapes.Cone((0, 0, 2), (0, 0, -1), 1.5, 0.6)
+    assert abs(cyl.surface_area() - (2 * np.pi * 0.25 + 2 * np.pi * 0.5 * 2.0)) < 1e-12
+    assert abs(cone.surface_area() - (np.pi * 0.36 + np.pi * 0.6 * np.hypot(0.6, 1.5))) < 1e-12
+    axis = np.array([1, 1, 0]) / 2 ** 0.5
+    on_side = 0
+    for _ in range(300):
+        p, n = cyl.random_surface_point_and_normal(rng)
+        rel = p - np.array([0.5, 0.2, 0.1])
+        z, rho = rel.dot(axis), np.linalg.norm(rel - rel.dot(axis) * axis)
+        assert abs(np.linalg.norm(n) - 1) < 1e-12 and -1e-9 <= z <= 2 + 1e-9 and rho <= 0.5 + 1e-9
+        lateral = abs(rho - 0.5) < 1e-9 and abs(n.dot(axis)) < 1e-9
+        cap = (abs(z) < 1e-9 and n.dot(axis) < -1 + 1e-9) or (abs(z - 2) < 1e-9 and n.dot(axis) > 1 - 1e-9)
+        assert lateral or cap
+        on_side += lateral
+        assert np.linalg.norm(p - cyl.center_and_min_sampling_distance()[0]) <= 0.5 * cyl.center_and_min_sampling_distance()[1] + 1e-9
+    assert abs(on_side / 300.0 - 0.8) < 0.08                    # lateral share 2 pi R h / total = 0.8
+    for _ in range(300):
+        p, n = cone.random_surface_point_and_normal(rng)
+        rel = p - np.array([0, 0, 2.0])
+        depth, rho = -rel[2], np.hypot(rel[0], rel[1])           # along the axis (0, 0, -1)
+        assert abs(np.linalg.norm(n) - 1) < 1e-12 and -1e-9 <= depth <= 1.5 + 1e-9
+        lateral = abs(rho - 0.6 * depth / 1.5) < 1e-9 and abs(n.dot(rel)) < 1e-9      # normal is perpendicular to the generator
+        base = abs(depth - 1.5) < 1e-9 and n[2] < -1 + 1e-9
+        assert lateral or base
+    # stretched round bodies are refused like a scaled Sphere light
+    squashed = shapes.Cylinder((0, 0, 0), (0, 0, 1), 1.0, 1.0)
+    squashed.linear_transform(scaling=(1, 2, 1))
+    with pytest.raises(RuntimeError):
+        squashed.surface_area()
