@@ -45,6 +45,14 @@ __constant__ int clr_log_floats = CLR_LOG_FLOATS;              // read by the ho
 __constant__ float4 clr_lights[{{ [renderer.light_table.size // 4, 2]|max }}];
 ### endif
 
+### if renderer.bidirectional
+template<class CLR_G>
+CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint whichobject,
+    const uint which_subobject, const uint inside, const int diffusions_left,
+    const vec3 dest, const int light_id,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g);
+### endif
+
 {% include 'shader.hip' %}
 
 // ---- shape functions
@@ -265,11 +273,14 @@ CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last,
                                            vector_data, integer_data);
     float shadow_mask = 0.0f;
 ### if renderer.bidirectional
-    if (!is_last)
+    // with a debug dump the visibility of the light point is evaluated for every ray, as the
+    // reference does; otherwise inside the diffuse stage, for the lanes that use it (shader.hip)
+    if (dbg && !is_last)
         shadow_mask = clr_light_visibility(s.pos, normal, whichobject, which_subobject, s.inside,
             s.diffusions_left, B.light_point, B.light_id, vector_data, integer_data, clr_g);
 ### endif
-    const bool alive = clr_shade(s, normal, isec_dist, shadow_mask, B, is_last, cmask, img
+    const bool alive = clr_shade(s, normal, isec_dist, shadow_mask, dbg == nullptr, B, is_last, cmask, img,
+                                 vector_data, integer_data, clr_g
 ### if not shader.rgb
         , material_row
 ### endif

@@ -102,8 +102,18 @@ struct BounceSample {                    // one record of the random tape (SURVE
 // Runs the stage pipeline for one path segment that ended at s.pos (surface s.whichobject,
 // normal n, segment length last_dist).  Adds radiance to `img`.  Returns false if the path
 // is finished (last segment, or culled).
-CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const float shadow_mask,
-                      const BounceSample &B, const bool is_last, const vec3 cmask, clr_acc &img
+// The visibility of the light point (the second sweep over all objects, main.hip) is needed by
+// one term only: the next-event estimate inside the diffuse stage.  It is therefore evaluated
+// there, for the lanes that get that far (lazy_visibility; a path that ends on a surface
+// without a diffuse part - sky, lamp - or leaves by a mirror reflection never asks for it; same
+// operands, same result: no stage before the diffuse one changes position, surface or medium
+// without ending the pipeline).  With a debug dump the sweep runs up front as in the reference,
+// because the dump records the mask of every ray.
+template<class CLR_G>
+CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const float eager_shadow_mask,
+                      const bool lazy_visibility,
+                      const BounceSample &B, const bool is_last, const vec3 cmask, clr_acc &img,
+                      const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g
 ### if not shader.rgb
                       , const float * __restrict__ material_scalars
 ### endif
@@ -285,6 +295,10 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
                     vec3 shadow_ray = B.light_point - s.pos;
                     s.suppress_emission = B.light_id;
                     if (dot(shadow_ray, n) > 0 && dot(shadow_ray, B.light_normal) < 0) {
+                        // diffusions_left was at least 1 before this stage took one
+                        const float shadow_mask = !lazy_visibility ? eager_shadow_mask :
+                            clr_light_visibility(s.pos, n, s.whichobject, s.which_subobject, s.inside, 1,
+                                                 B.light_point, B.light_id, vector_data, integer_data, clr_g);
                         const float shadow_dist = length(shadow_ray);
                         shadow_ray = fast_normalize(shadow_ray);
                         const float geom = dot(n, shadow_ray) / CLR_PI_F
