@@ -63,7 +63,7 @@ struct clr_ctx {
 struct clr_program {
     clr_ctx *ctx;
     hipModule_t module;
-    hipFunction_t render, first_hit, reduce_log;
+    hipFunction_t render, render_debug, first_hit, reduce_log;
     int rng_mode;      // 1: the program draws per-pixel random numbers, 0: it reads the bounce tape
     int split_mode;    // 1: clr_render logs addends per pass and clr_reduce_log sums them
     int log_floats;    // floats per (pass, pixel) of the addend log (module global clr_log_floats)
@@ -265,6 +265,7 @@ int load_program(clr_ctx *ctx, const void *binary, clr_program **out) {
     }
     // a program for clr_launch only (unit kernels) need not hold the two fixed entry kernels
     if (hipModuleGetFunction(&prog->render, prog->module, "clr_render") != hipSuccess) prog->render = nullptr;
+    if (hipModuleGetFunction(&prog->render_debug, prog->module, "clr_render_debug") != hipSuccess) prog->render_debug = nullptr;
     if (hipModuleGetFunction(&prog->first_hit, prog->module, "clr_first_hit") != hipSuccess) prog->first_hit = nullptr;
     if (hipModuleGetFunction(&prog->reduce_log, prog->module, "clr_reduce_log") != hipSuccess) prog->reduce_log = nullptr;
     prog->rng_mode = 0;
@@ -387,6 +388,10 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
         return fail("clr_render_passes: `regenerate` does not match the form of clr_render the program was generated in");
     if (a->debug_dump && a->n_passes != 1)
         return fail("clr_render_passes: debug_dump needs n_passes == 1");
+    if (a->debug_dump && !prog->render_debug)
+        return fail("clr_render_passes: debug_dump given, but the program has no kernel clr_render_debug");
+    // the dump is written by a kernel of its own; clr_render carries no code for it
+    hipFunction_t render = a->debug_dump ? prog->render_debug : prog->render;
     if (static_log) {
         if (!prog->split_mode)
             return fail("clr_render_passes_static_log: only pass-split programs use a log; call clr_render_passes");
@@ -425,7 +430,7 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     const unsigned block[3] = {kBlock, 1, 1};
     if (!prog->split_mode) {
         const unsigned grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
-        return launch(prog->ctx, prog->render, grid, block, args, stream, elapsed_ms);
+        return launch(prog->ctx, render, grid, block, args, stream, elapsed_ms);
     }
     // pass-split program: n_pixels x pass_groups lanes write the log, then one lane per pixel sums it
     // whole waves per group, so that no wave straddles two groups (main.hip)
@@ -437,7 +442,7 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     void *reduce_args[] = {&img, &log_in, &n_pixels, &n_passes};
     hipStream_t s = (hipStream_t)stream;
     if (elapsed_ms) CLR_TRY(hipEventRecord(prog->ctx->ev_start, s));
-    CLR_TRY(hipModuleLaunchKernel(prog->render, grid[0], 1, 1, kBlock, 1, 1, 0, s, args, nullptr));
+    CLR_TRY(hipModuleLaunchKernel(render, grid[0], 1, 1, kBlock, 1, 1, 0, s, args, nullptr));
     CLR_TRY(hipModuleLaunchKernel(prog->reduce_log, reduce_grid[0], 1, 1, kBlock, 1, 1, 0, s, reduce_args, nullptr));
     if (elapsed_ms) {
         CLR_TRY(hipEventRecord(prog->ctx->ev_stop, s));

@@ -342,15 +342,20 @@ static __device__ __attribute__((noinline)) bool clr_segment_generic(PathState *
             float4 *d = dbg ? dbg + ((size_t){{ segment }} * n_pixels + k) * CLR_DBG_STRIDE : nullptr;
             const float *material_row = material_rows + (size_t){{ pass }} * CLR_MATERIAL_ROW;
 {%- endmacro %}
+// The kernel exists twice: clr_render, and clr_render_debug for launches with a debug dump.  In
+// clr_render the dump pointer is a null constant, so the stores of the dump and the up-front
+// light visibility sweep that the dump needs (clr_segment) are not part of its code at all.
+{%- macro render_kernel(kernel_name, debug) %}
 extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_per_simd if renderer.min_waves_per_simd else '' }})
-clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
+{{ kernel_name }}(float4 * __restrict__ img, const float4 * __restrict__ cam,
            const float4 * __restrict__ pass_tape, const float4 * __restrict__ bounce_tape,
            const float * __restrict__ material_rows,
            const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-           const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg,
+           const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg_argument,
            const uint rng_seed_lo, const uint rng_seed_hi, const int first_pass, const int first_ray,
            float * __restrict__ pass_log, const int pass_groups, const int pass_stride)
 {
+    float4 * __restrict__ const dbg = {{ 'dbg_argument' if debug else 'nullptr' }};
 ### if renderer.split_passes
     // pass-split mode: lane (k, group) walks the passes [group * per_group, ...) of pixel k and
     // logs what it would have added to the pixel (layout: clr_acc, shader.hip)
@@ -529,6 +534,9 @@ clr_render(float4 * __restrict__ img, const float4 * __restrict__ cam,
     if (in_image) img[k] = make_float4(acc.v.x, acc.v.y, acc.v.z, img0.w);
 ### endif
 }
+{%- endmacro %}
+{{ render_kernel('clr_render', false) }}
+{{ render_kernel('clr_render_debug', true) }}
 
 ### if renderer.split_passes
 // Second step of pass-split mode: the logged addends of every pass, added to the pixel in pass
