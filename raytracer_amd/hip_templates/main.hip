@@ -148,7 +148,8 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
 ### set group = loop.index0
 ### if renderer.bake_parameters
     ### for i in range(count)
-    if ({{ offset+1+i }} != light_id)
+    // (a ray that an earlier object has blocked stays blocked: the remaining tests cannot change it)
+    if ({{ offset+1+i }} != light_id && shadow_mask != 0.0f)
         {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,
             shadow_mask, vector_data, integer_data,
             {{ offset+1+i }}, clr_params + {{ renderer.group_param_base[group] + i*renderer.group_param_stride[group] }},
@@ -157,7 +158,7 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
 ### else
     #pragma unroll {{ [count, 8]|min }}
     for (int i = 0; i < {{ count }}; ++i)
-        if ({{ offset+1 }} + i != light_id)
+        if ({{ offset+1 }} + i != light_id && shadow_mask != 0.0f)
             {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,
                 shadow_mask, vector_data, integer_data,
                 {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[group] }} + i*{{ renderer.group_param_stride[group] }}, 0, clr_g);
