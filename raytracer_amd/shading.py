@@ -10,8 +10,9 @@ scenes/default_scenes.py:9-78; `install_flat_aliases()` maps the module names `s
 
 The reference loads the CIE 1931 2-degree table from ``data/cie-1931.csv``, a file it does not
 ship; that file is used when present, otherwise the analytic multi-lobe fit of
-Wyman, Sloan & Shirley (2013) to the same observer, so spectral parity with the reference is
-unpinned (DESIGN.md).
+Wyman, Sloan & Shirley (2013) to the same observer.  Everything downstream of the table is
+pinned against the reference's own code run on this table (tests/golden/spectral-*.npz,
+DESIGN.md section 4); only the table values themselves are this package's.
 """
 import os
 import numpy as np

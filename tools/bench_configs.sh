@@ -1,6 +1,10 @@
+# Bench lines of the BASELINE configurations other than the default one (run through gpurun).
+# BENCH_BASELINE=1 adds the CPU baseline and with it the roofline fraction of every line.
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-run() { timeout -k 10 300 python bench.py --no-cpu-baseline "$@" 2>>gpurun_out/configs.err || exit 1; }
+EXTRA="--no-cpu-baseline"
+[ -n "$BENCH_BASELINE" ] && EXTRA="--cpu-seconds 6"
+run() { timeout -k 10 400 python bench.py $EXTRA "$@" 2>>gpurun_out/configs.err || exit 1; }
 {
 run --scene scene-three-objects
 run --scene scene-test --size 320x240 --passes-per-step 16
