@@ -219,6 +219,9 @@
             pool_best[tid] = ~0ull;
 
             // ---- B: inclusive prefix sums of the counts over the lanes of this call
+            // (neighbouring rays cross empty space together: a step in which no lane of the wave
+            // stands in a leaf with triangles goes straight on to the hop)
+            if (__any(count > 0)) {
             pool_scan[wave_base + rank] = count;
             POOL_SYNC();
             for (int d = 1; d < n_lanes; d <<= 1) {
@@ -280,6 +283,7 @@
                     }
                 }
                 cur = next;
+            }
             }
             POOL_SYNC();
 
