@@ -79,25 +79,21 @@ typedef vec2 ia_type;
 #define ia_mul_pos_exact(a, ex) ((a) * (float)(ex))
 #define ia_mul_neg_exact(a, ex) (ia_neg(a) * -(float)(ex))
 
+// |a|: the three cases of the reference (static.cl:13-18) without branches, same numbers
 CLR_FN ia_type ia_abs(ia_type a) {
-    if (ia_begin(a) >= 0.0f) return a;
-    if (ia_end(a) <= 0.0f) return ia_neg(a);
-    return ia_new(0.0f, fmaxf(-ia_begin(a), ia_end(a)));
+    return ia_new(fmaxf(fmaxf(ia_begin(a), -ia_end(a)), 0.0f), fmaxf(-ia_begin(a), ia_end(a)));
 }
 
+// Interval product.  The reference (static.cl:20-47) picks the two bounding products by a case
+// analysis on the signs of the end points; the lanes of a wave take different cases and the wave
+// then runs all of them.  Rounding is monotone, so the products the case analysis picks are the
+// smallest and the largest of the four end-point products: the branch-free form returns the same
+// numbers (at most the sign of a zero bound can differ, which no comparison with zero and no
+// non-zero sum or product downstream can see).  The oracle keeps the case analysis.
 CLR_FN ia_type ia_mul(ia_type a, ia_type b) {
-    if (ia_contains_zero(a)) {
-        if (ia_contains_zero(b)) {
-            return ia_new(fminf(ia_begin(a) * ia_end(b), ia_begin(b) * ia_end(a)),
-                          fmaxf(ia_begin(a) * ia_begin(b), ia_end(a) * ia_end(b)));
-        }
-        ia_type tmp = b; b = a; a = tmp;
-    }
-    if (ia_end(a) < 0.0f) { a = ia_neg(a); b = ia_neg(b); }
-    // now ia_begin(a) > 0
-    if (ia_end(b) < 0.0f) return ia_new(ia_end(a) * ia_begin(b), ia_begin(a) * ia_end(b));
-    else if (ia_contains_zero(b)) return ia_new(ia_end(a) * ia_begin(b), ia_end(a) * ia_end(b));
-    else return a * b;
+    const float p0 = ia_begin(a) * ia_begin(b), p1 = ia_begin(a) * ia_end(b),
+                p2 = ia_end(a) * ia_begin(b), p3 = ia_end(a) * ia_end(b);
+    return ia_new(fminf(fminf(p0, p1), fminf(p2, p3)), fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)));
 }
 
 CLR_FN ia_type ia_pow2(ia_type a) { ia_type ab = ia_abs(a); return ab * ab; }
