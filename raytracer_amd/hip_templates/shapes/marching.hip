@@ -160,10 +160,19 @@
         vec3 pos = march_begin * ray + origin;
 
         for (int i = 0; i < MAX_ITER; i++) {
-            vec4 q = make_vec4(pos, 0.0f), qd = make_vec4(1.0f, 0.0f, 0.0f, 0.0f);
             // (the reference's directional-derivative chain only runs when the ray starts on
             //  this surface, which returned above)
-            for (int k = 0; k < {{ obj.julia_itr }}; ++k) {
+            // The derivative starts at (1, 0, 0, 0), so its first update 2 q (1, 0, 0, 0) is 2 q: for
+            // finite q the general product returns exactly that, up to the sign of components that
+            // are zero, which no later sum with a non-zero term and no length can see.  The compiler
+            // may not drop the 28 operations with the zeros (x * 0 is not 0 for every x); here they are.
+            ### if obj.julia_itr >= 1
+            vec4 q = make_vec4(pos, 0.0f), qd = 2*q;
+            q = quaternion_square(q) + c;
+            ### else
+            vec4 q = make_vec4(pos, 0.0f), qd = make_vec4(1.0f, 0.0f, 0.0f, 0.0f);
+            ### endif
+            for (int k = 1; k < {{ obj.julia_itr }}; ++k) {
                 qd = 2*quaternion_mult(q, qd);
                 q = quaternion_square(q) + c;
             }
