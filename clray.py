@@ -67,7 +67,10 @@ def main():
     image = Image(RAW_OUTPUT_FILE if args.append else None, settings=scene.image)
     n_rays = scene.image.size[0] * scene.image.size[1]
     shard = multi_gpu.Shard(args.partition, rank, world, n_rays)
-    if world > 1:
+    # CLRAY_FORCE_DIST=1 runs the several-GPU code path (torch accumulator, RCCL exchange) with
+    # whatever number of workers there is, also one (development check on a one-GPU box)
+    use_dist = world > 1 or bool(os.environ.get('CLRAY_FORCE_DIST'))
+    if use_dist:
         if args.seed is None:
             raise SystemExit("--gpus needs --seed: every GPU draws the same global sequence of passes")
         import torch
@@ -81,7 +84,7 @@ def main():
     if scene.samples_per_pixel >= 64:
         renderer.tune_occupancy(passes=8)       # pays off for long renders only
     acc = renderer.acc
-    if world > 1:
+    if use_dist:
         # the accumulator lives in a torch tensor so that RCCL can combine the ranks' results
         frame = torch.zeros((shard.frame_rows, 4), dtype=torch.float32, device='cuda')
         renderer.use_image_buffer(shard.my_rows(frame)[:renderer.n_pixels].data_ptr())
@@ -89,10 +92,12 @@ def main():
 
     def whole_image():
         """(H, W, 3) sums over all passes of all GPUs so far (every rank takes part, rank 0 uses it)."""
-        if world == 1:
+        if not use_dist:
             return renderer.get_image()
         combined.copy_(frame)
         shard.combine(combined, dist)
+        if world == 1:
+            dist.all_reduce(combined)            # one rank: the sum of one accumulator
         from raytracer_amd.renderer import unpermute_rays
         return unpermute_rays(combined[:n_rays, :3].cpu().numpy(), renderer.full_image_order,
                               renderer.img_shape).astype(np.float64)
@@ -128,7 +133,7 @@ def main():
                 image.show(imgdata)
             image.save_raw(RAW_OUTPUT_FILE, imgdata)
             try:
-                if world > 1:
+                if use_dist:
                     raise NotImplementedError       # the device tone mapper reads one GPU's accumulator
                 # 8-bit image straight from the device accumulator (tonemap.py)
                 from PIL import Image as PilImage
@@ -138,7 +143,7 @@ def main():
             acc.output_profiling_info()
     if rank == 0:
         acc.output_profiling_info()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

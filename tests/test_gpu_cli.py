@@ -1,0 +1,53 @@
+"""clray.py end to end on the GPU: the reference's command line (clray.py:30-39) with a scene
+file, outputs out.png / out.raw.npy, --append, and the several-GPU code path run with one worker."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_scene
+from raytracer_amd.renderer import Renderer
+
+pytestmark = pytest.mark.gpu
+
+SCENE = os.path.join(ROOT, 'raytracer_amd', 'scenes', 'scene-dev.py')
+
+
+def run_cli(cwd, *flags, env=None, launcher=()):
+    cmd = [sys.executable] + list(launcher) + [os.path.join(ROOT, 'clray.py'), '-n', '--size', '64x48', '--spp', '12',
+                                               '--seed', '5', '-itr', '8'] + list(flags) + [SCENE]
+    full_env = dict(os.environ, **(env or {}))
+    out = subprocess.run(cmd, cwd=str(cwd), env=full_env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=280)
+    assert out.returncode == 0, out.stdout.decode()[-2000:]
+    return out.stdout.decode()
+
+
+def expected_sums():
+    r = Renderer(load_scene('scene-dev', (64, 48), samples_per_pixel=12), seed=5)
+    r.render_samples(0, 12)
+    return r.get_image()
+
+
+def test_command_line_renders_saves_and_appends(tmp_path):
+    log = run_cli(tmp_path)
+    assert '12/12' in log and 'rays/s' in log and 'image mean' in log
+    raw = np.load(tmp_path / 'out.raw.npy')
+    want = expected_sums()
+    assert raw.shape == (48, 64, 3) and np.array_equal(raw, want)      # batching changes no bit
+    assert (tmp_path / 'out.png').stat().st_size > 500
+    run_cli(tmp_path, '-a')                                            # the reference's resume mode
+    assert np.allclose(np.load(tmp_path / 'out.raw.npy'), 2 * want)
+
+
+def test_several_gpu_code_path_with_one_worker(tmp_path):
+    """`--gpus` goes through torch.distributed (RCCL): accumulator in a torch tensor, exchange
+    step, image assembled from the full ray order.  With one worker the sums must equal the plain
+    run's bit for bit, for both partitions."""
+    want = expected_sums()
+    launcher = ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                '--master-port', str(29600 + os.getpid() % 300)]
+    for partition in ('passes', 'tiles'):
+        run_cli(tmp_path, '--gpus', '1', '--partition', partition, env={'CLRAY_FORCE_DIST': '1'}, launcher=launcher)
+        assert np.array_equal(np.load(tmp_path / 'out.raw.npy'), want), partition
