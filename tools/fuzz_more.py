@@ -5,7 +5,7 @@ from test_gpu_fuzz import random_scene, bits
 from raytracer_amd.renderer import Renderer
 from oracle import oracle
 bad = 0
-for seed in range(300, 348):
+for seed in range(int(os.environ.get("FUZZ_FIRST", 300)), int(os.environ.get("FUZZ_LAST", 348))):
     for mode in ('tape', 'philox'):
         for split in (True, False):
             r = Renderer(random_scene(seed), seed=seed, rng_mode=mode, split_passes=split)
