@@ -6,20 +6,20 @@
 ### from 'tracer.hip' import tracer_function_base, normal_function_base
 ### from 'helpers.hip' import vec3_literal
 
-{#- clip [lo_var, hi_var] to a bounding sphere of radius R about the origin; `return`s from
-    the enclosing tracer function on a miss (reference objects/bounding_volumes.cl:3-27) -#}
+{#- Part of the ray inside a sphere of radius R about the local origin, cut to [0, t_limit]:
+    assigns it to lo_var / hi_var, or `return`s from the enclosing tracer function when there is
+    none (reference objects/bounding_volumes.cl:3-27).  `ray` is a unit vector, so the quadratic
+    is t^2 - 2 m t + (|o|^2 - R^2) with m = -ray.o. -#}
 ### macro sphere_bounding_volume(R, lo_var, hi_var)
     {
-        const float bound_r2 = {{ (R*R)|float }}f;
-        float half_b = -dot(ray, origin);
-        float o_len2 = dot(origin, origin);
-        bool inside_bound = o_len2 < bound_r2;
-        if (half_b <= 0 && !inside_bound) return;
-        const float disc = half_b*half_b - o_len2 + bound_r2;
+        const float r2 = {{ (R*R)|float }}f;
+        const float m = -dot(ray, origin), oo = dot(origin, origin);
+        if (m <= 0 && !(oo < r2)) return;          // outside and heading away
+        const float disc = m*m - oo + r2;
         if (disc < 0) return;
-        const float root = native_sqrt(disc);
-        {{ lo_var }} = fmaxf(half_b - root, 0.0f);
-        {{ hi_var }} = fminf(half_b + root, t_limit);
+        const float h = native_sqrt(disc);
+        {{ lo_var }} = fmaxf(m - h, 0.0f);
+        {{ hi_var }} = fminf(m + h, t_limit);
         if ({{ hi_var }} <= {{ lo_var }}) return;
     }
 ### endmacro
@@ -50,9 +50,13 @@
 ### endmacro
 
 {#- implicit surface f = 0 located by interval arithmetic along the ray
-    (reference objects/ImplicitSurface.cl:6-120).  The parameter interval t is advanced in
-    steps; when f(t) may contain the surface the interval is halved until it is shorter than
-    the precision, otherwise the step is doubled again after two clean steps. -#}
+    (reference objects/ImplicitSurface.cl:6-120).  The ray is examined piece by piece: f over a
+    piece is bounded with interval arithmetic; a piece that may hold a sign change of the wanted
+    direction is halved until it is shorter than the precision (its centre is the hit), a piece that
+    cannot is passed, and after two passed pieces in a row the piece length doubles.
+    The generated expressions (objects/marching.py) read x, y, z, t, ray_*, origin_* and assign f
+    and df: sympy orders sums and products by symbol name, so these names fix the order of the
+    floating-point operations and stay as the reference has them. -#}
 
 ### macro ImplicitSurface__tracer(obj)
     ### call tracer_function_base(obj)
@@ -60,78 +64,64 @@
         if (on_surface) return;
         ### endif
 
-        ia_type t;
+        ia_type t;                               // the piece of the ray under examination
         ### if obj.bndR
             {{ sphere_bounding_volume(obj.bndR, 'ia_begin(t)', 'ia_end(t)') }}
         ### else
-            ia_begin(t) = 0.0f;
-            ia_end(t) = t_limit;
+            t = ia_new(0.0f, t_limit);
         ### endif
-        const float t_max = ia_end(t);
+        const float t_stop = ia_end(t);
+        const int piece_budget = {{ obj.max_itr }};
+        const float resolution = {{ obj.precision|float }}f;
 
-        const int MAX_ITER = {{ obj.max_itr }};
-        const float TARGET_EPS = {{ obj.precision|float }}f;
-        const float FRACTION = 0.5f;
-        const float SELF_MAX_BEGIN_STEP = 0.1f;
+        const ia_type ray_x = ia_new_exact(ray.x), ray_y = ia_new_exact(ray.y), ray_z = ia_new_exact(ray.z);
+        const ia_type origin_x = ia_new_exact(origin.x), origin_y = ia_new_exact(origin.y),
+                      origin_z = ia_new_exact(origin.z);
 
-        ia_type f, df;
-        ia_type x, y, z;
-        float step;
-        int steps_since_subdiv = 0;
+        // leaving the own surface: a short first piece, so that the derivative test below can tell
+        // the start point from the next root
+        if (on_surface) ia_end(t) = fminf(ia_end(t), ia_begin(t) + 0.1f);
 
-        const ia_type ray_x = ia_new_exact(ray.x);
-        const ia_type ray_y = ia_new_exact(ray.y);
-        const ia_type ray_z = ia_new_exact(ray.z);
-        const ia_type origin_x = ia_new_exact(origin.x);
-        const ia_type origin_y = ia_new_exact(origin.y);
-        const ia_type origin_z = ia_new_exact(origin.z);
-        int need_subdiv;
+        int passed = 0;                          // pieces passed since the last halving
+        for (int piece = 0; piece < piece_budget; ++piece) {
+            if (ia_begin(t) >= t_stop) return;
+            ia_end(t) = ia_end(t) > t_stop ? t_stop : ia_end(t);
 
-        if (on_surface) ia_end(t) = fminf(ia_end(t), ia_begin(t) + SELF_MAX_BEGIN_STEP);
-
-        for (int i = 0; i < MAX_ITER; i++) {
-            if (ia_begin(t) >= t_max) return;
-            if (ia_end(t) > t_max) ia_end(t) = t_max;
-
-            x = ia_mul(ray_x, t) + origin_x;
-            y = ia_mul(ray_y, t) + origin_y;
-            z = ia_mul(ray_z, t) + origin_z;
-
+            const ia_type x = ia_mul(ray_x, t) + origin_x,
+                          y = ia_mul(ray_y, t) + origin_y,
+                          z = ia_mul(ray_z, t) + origin_z;
+            ia_type f;
             ### if obj.f_code_template() == 'QuaternionJuliaSet'
                 {{ julia_interval_f(obj) }}
             ### else
                 {{ obj.f_code }}
             ### endif
 
-            step = ia_len(t);
-            need_subdiv = 0;
-
-            if ((inside && ia_end(f) > 0) || (!inside && ia_begin(f) < 0)) {
-                need_subdiv = 1;
-                if (on_surface) {
-                    ### if obj.f_code_template() == 'QuaternionJuliaSet'
-                        {{ julia_interval_df(obj) }}
-                    ### else
-                        {{ obj.df_code }}
-                    ### endif
-                    if (!ia_contains_zero(df)) {
-                        if ((ia_end(df) < 0) == inside) need_subdiv = 0;
-                    }
-                }
-                if (need_subdiv) {
-                    if (step < TARGET_EPS || i == MAX_ITER-1) {
-                        *t_hit = ia_center(t);
-                        return;
-                    }
-                    step *= FRACTION;
-                    ia_end(t) = ia_begin(t) + step;
-                    steps_since_subdiv = 0;
-                    continue;
-                }
+            // f > 0 outside the body: a ray inside looks for f reaching above zero, one outside below
+            bool may_cross = inside ? ia_end(f) > 0 : ia_begin(f) < 0;
+            if (may_cross && on_surface) {
+                ia_type df;
+                ### if obj.f_code_template() == 'QuaternionJuliaSet'
+                    {{ julia_interval_df(obj) }}
+                ### else
+                    {{ obj.df_code }}
+                ### endif
+                // f moves away from zero over the whole piece: it is the start point's own root
+                if (!ia_contains_zero(df) && (ia_end(df) < 0) == inside) may_cross = false;
             }
-            steps_since_subdiv++;
-            if (steps_since_subdiv > 1) step /= FRACTION;
-            t = ia_new(ia_end(t), ia_end(t) + step);
+
+            float width = ia_len(t);
+            if (may_cross) {
+                if (width < resolution || piece == piece_budget - 1) {
+                    *t_hit = ia_center(t);
+                    return;
+                }
+                ia_end(t) = ia_begin(t) + width * 0.5f;
+                passed = 0;
+            } else {
+                if (++passed > 1) width *= 2.0f;
+                t = ia_new(ia_end(t), ia_end(t) + width);
+            }
         }
     ### endcall
 ### endmacro
@@ -149,17 +139,14 @@
 ### macro QuaternionJuliaSet2__tracer(obj)
     ### call tracer_function_base(obj)
         if (on_surface) return;
-        float march_begin, march_end;
-        {{ sphere_bounding_volume(obj.bndR, 'march_begin', 'march_end') }}
+        float travelled, t_stop;
+        {{ sphere_bounding_volume(obj.bndR, 'travelled', 't_stop') }}
 
-        const int MAX_ITER = {{ obj.max_itr }};
-        const float TARGET_EPS = {{ obj.precision|float }}f;
-        const float MAX_STEP = {{ obj.max_step|float }}f;
+        const float resolution = {{ obj.precision|float }}f, longest_step = {{ obj.max_step|float }}f;
         const vec4 c = {{ obj.c_as_float4 }};
-        float step, dist = march_begin;
-        vec3 pos = march_begin * ray + origin;
+        vec3 at = travelled * ray + origin;
 
-        for (int i = 0; i < MAX_ITER; i++) {
+        for (int n = 0; n < {{ obj.max_itr }}; ++n) {
             // (the reference's directional-derivative chain only runs when the ray starts on
             //  this surface, which returned above)
             // The derivative starts at (1, 0, 0, 0), so its first update 2 q (1, 0, 0, 0) is 2 q: for
@@ -167,26 +154,26 @@
             // are zero, which no later sum with a non-zero term and no length can see.  The compiler
             // may not drop the 28 operations with the zeros (x * 0 is not 0 for every x); here they are.
             ### if obj.julia_itr >= 1
-            vec4 q = make_vec4(pos, 0.0f), qd = 2*q;
+            vec4 q = make_vec4(at, 0.0f), qd = 2*q;
             q = quaternion_square(q) + c;
             ### else
-            vec4 q = make_vec4(pos, 0.0f), qd = make_vec4(1.0f, 0.0f, 0.0f, 0.0f);
+            vec4 q = make_vec4(at, 0.0f), qd = make_vec4(1.0f, 0.0f, 0.0f, 0.0f);
             ### endif
             for (int k = 1; k < {{ obj.julia_itr }}; ++k) {
                 qd = 2*quaternion_mult(q, qd);
                 q = quaternion_square(q) + c;
             }
-            float l = length(q);
+            const float l = length(q);
             // `0.5 * l * log(l) / length(qd)` with a double literal: one rounding at the end
-            step = (float)(0.5 * (double)l * (double)clr_logf(l) / (double)length(qd));
-            step = fminf(step, MAX_STEP);
-            if (step < TARGET_EPS) {
-                *t_hit = dist + step;
+            const float estimate = (float)(0.5 * (double)l * (double)clr_logf(l) / (double)length(qd));
+            const float step = fminf(estimate, longest_step);
+            if (step < resolution) {
+                *t_hit = travelled + step;
                 return;
             }
-            dist += step;
-            if (dist > march_end) return;
-            pos += step * ray;
+            travelled += step;
+            if (travelled > t_stop) return;
+            at += step * ray;
         }
     ### endcall
 ### endmacro
@@ -220,45 +207,40 @@
         ### if obj.no_self_intersection
         if (on_surface) return;
         ### endif
-        float t, t_end;
-        float sign = 1.0f;
-        if (inside) sign = -1.0f;
+        float t, t_stop;
         ### if obj.bndR
-            {{ sphere_bounding_volume(obj.bndR, 't', 't_end') }}
+            {{ sphere_bounding_volume(obj.bndR, 't', 't_stop') }}
         ### else
             t = 0.0f;
-            t_end = t_limit;
+            t_stop = t_limit;
         ### endif
 
-        const int MAX_ITER = {{ obj.max_itr }};
-        const float EPS = {{ obj.precision|float }}f;
-        float x, y, z;
-        float last_dist = 0.0f;
-        float derivative = -1.0f;
+        const float resolution = {{ obj.precision|float }}f;
+        const float side = inside ? -1.0f : 1.0f;   // the field is positive outside the body
+        float previous = 0.0f;                      // distance at the step before
+        float x, y, z;                              // read by the user's code
 
-        for (int i = 0; i < MAX_ITER; i++) {
-            if (t > t_end) return;
-            const vec3 pos = origin + t * ray;
-            x = pos.x; y = pos.y; z = pos.z;
+        for (int n = 0; n < {{ obj.max_itr }}; ++n) {
+            if (t > t_stop) return;
+            const vec3 at = origin + t * ray;
+            x = at.x; y = at.y; z = at.z;
             float dist = 0.0f;
             {
             {{ obj.tracer_code }};
             }
-            dist *= sign;
+            dist *= side;
 
-            if (dist < EPS) {
-                if (on_surface) {
-                    // leaving the own surface: accept only once the distance decreases
-                    if (i > 0) derivative = dist - last_dist;
-                    else derivative = 0.0f;
-                }
-                if (derivative < 0.0f) {
-                    if (t < t_end) *t_hit = t;
+            if (dist < resolution) {
+                // A ray that leaves this surface starts within the resolution of it: it may stop
+                // only where the distance has been falling (never at its first sample).
+                const bool falling = on_surface ? (n > 0 && dist - previous < 0.0f) : true;
+                if (falling) {
+                    if (t < t_stop) *t_hit = t;
                     return;
                 }
             }
-            t += fmaxf(dist, EPS);
-            last_dist = dist;
+            t += fmaxf(dist, resolution);
+            previous = dist;
         }
     ### endcall
 ### endmacro
