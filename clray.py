@@ -139,7 +139,7 @@ def main():
                 from PIL import Image as PilImage
                 PilImage.fromarray(renderer.get_display_image(scene.image, base=image.data), 'RGB').save(PNG_OUTPUT_FILE)
             except NotImplementedError:
-                image.save_png(PNG_OUTPUT_FILE, imgdata)        # flares, several GPUs: host pipeline
+                image.save_png(PNG_OUTPUT_FILE, imgdata)        # several GPUs, other reductions: host pipeline
             acc.output_profiling_info()
     if rank == 0:
         acc.output_profiling_info()

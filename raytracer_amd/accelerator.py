@@ -418,6 +418,8 @@ class Accelerator:
                 holders.append(ctypes.c_void_p(a.ptr))
             elif a is None:
                 holders.append(ctypes.c_void_p(0))
+            elif isinstance(a, np.int64):
+                holders.append(ctypes.c_longlong(int(a)))       # a Python int stays a C int
             elif isinstance(a, (np.integer, int)):
                 holders.append(ctypes.c_int(int(a)))
             elif isinstance(a, np.float64):

@@ -66,3 +66,94 @@ clr_tm_encode(const float4 * __restrict__ img, const double * __restrict__ base,
         dst[c] = (unsigned char)(v * 255.0);
     }
 }
+
+// ---- flares (reference imgutils.py:121-148): over-exposed values bleed into their
+// neighbourhood through a 9-tap gaussian (both axes, mirrored at the border) and then through a
+// 198-tap exponential tail along the rows axis (zero outside the frame).  The work planes are
+// (H, W, 3) binary64 in image order; the filters follow scipy.ndimage's correlate1d term by term
+// (symmetric form: centre first, then pairs from the outermost inwards; general form: taps in
+// ascending order), so that the sums round as on the host.  Built with -ffp-contract=off.
+
+// value after scaling and gamma, not clamped above, written in image order
+extern "C" __global__ void __launch_bounds__(256)
+clr_tm_linear(const float4 * __restrict__ img, const double * __restrict__ base,
+              const int2 * __restrict__ order, const int n_pixels, const int width,
+              const double floor_value, const double scale, const double inv_gamma,
+              double * __restrict__ plane)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pixels) return;
+    double rgb[3];
+    clr_tm_pixel(img, base, k, rgb);
+    const int2 rc = order[k];
+    double *dst = plane + ((size_t)rc.x * width + rc.y) * 3;
+    for (int c = 0; c < 3; ++c) {
+        double v = (rgb[c] - floor_value) * scale;
+        v = v > 0.0 ? v : 0.0;
+        dst[c] = pow(v, inv_gamma);
+    }
+}
+
+// numpy's clip(v, 0, limit) and the part of v above it, v - clip(v, 0, limit); limit < 0: v itself
+static __device__ __forceinline__ double clr_tm_kept(double v, double limit) {
+    return v < 0.0 ? 0.0 : (v > limit ? limit : v);
+}
+static __device__ __forceinline__ double clr_tm_excess(double v, double limit) {
+    return limit < 0.0 ? v : v - clr_tm_kept(v, limit);
+}
+
+// one 1-D correlation along an axis of the plane.  Element e lies at position
+// (e / stride) % length of its line; its neighbours are `stride` elements apart.
+// taps = 2 * reach + 1 mirrored (symmetric != 0), else `taps` weights starting `reach` before e.
+extern "C" __global__ void __launch_bounds__(256)
+clr_tm_correlate(const double * __restrict__ src, double * __restrict__ dst, const long n_elements,
+                 const long stride, const int length, const double * __restrict__ weights,
+                 const int taps, const int reach, const int symmetric, const double limit)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elements) return;
+    const int at = (int)((e / stride) % length);
+    const double *line = src + (e - at * stride);
+    double sum;
+    if (symmetric) {
+        const double *centre = weights + reach;
+        sum = clr_tm_excess(line[at * stride], limit) * centre[0];
+        for (int j = -reach; j < 0; ++j) {
+            int lo = at + j, hi = at - j;
+            // mirror about the edges of the samples: (d c b a | a b c d | d c b a)
+            while (lo < 0 || lo >= length) lo = lo < 0 ? -lo - 1 : 2 * length - 1 - lo;
+            while (hi < 0 || hi >= length) hi = hi < 0 ? -hi - 1 : 2 * length - 1 - hi;
+            sum += (clr_tm_excess(line[lo * stride], limit) + clr_tm_excess(line[hi * stride], limit)) * centre[j];
+        }
+    } else {
+        sum = 0.0;
+        for (int m = 0; m < taps; ++m) {
+            const int p = at - reach + m;
+            const double v = (p < 0 || p >= length) ? 0.0 : clr_tm_excess(line[p * stride], limit);
+            sum += v * weights[m];
+        }
+    }
+    dst[e] = sum;
+}
+
+// plane = clip(plane, 0, limit) + bleed
+extern "C" __global__ void __launch_bounds__(256)
+clr_tm_merge(double * __restrict__ plane, const double * __restrict__ bleed, const long n_elements,
+             const double limit)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elements) return;
+    plane[e] = clr_tm_kept(plane[e], limit) + bleed[e];
+}
+
+// 8 bit of clip(clip(plane, 0, limit) + bleed, 0, 1)
+extern "C" __global__ void __launch_bounds__(256)
+clr_tm_encode_plane(const double * __restrict__ plane, const double * __restrict__ bleed,
+                    const long n_elements, const double limit, unsigned char * __restrict__ out)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elements) return;
+    double v = clr_tm_kept(plane[e], limit) + bleed[e];
+    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    out[e] = (unsigned char)(v * 255.0);
+}

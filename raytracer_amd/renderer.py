@@ -632,8 +632,9 @@ class Renderer:
 
     def get_display_image(self, settings=None, base=None):
         """8-bit (H, W, 3) image of the sums so far, tone-mapped on the device (tonemap.py);
-        `base` = earlier sums to add.  Raises NotImplementedError for settings the device path
-        does not cover (flares, other reference functions): use imgutils.Image then."""
+        `base` = earlier sums to add; flares included.  Raises NotImplementedError for settings
+        the device path does not cover (reduction functions other than min / mean): use
+        imgutils.Image then."""
         from .tonemap import DeviceToneMapper
         if getattr(self, '_tone_mapper', None) is None:
             self._tone_mapper = DeviceToneMapper(self)

@@ -402,7 +402,15 @@ def test_device_tone_mapping_matches_host_pipeline(low_norm):
         diff = np.abs(got.astype(int) - want.astype(int))
         assert diff.max() <= 1 and (diff > 0).mean() < 1e-5
         assert want.std() > 10                                   # a real picture, not a flat field
+    # flares on a rendered frame (the light is over-exposed), then a reduction the device lacks
     settings.flares = True
+    want = Image(settings=settings)._to_24bit(sums.copy())
+    got = r.get_display_image(settings)
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-5
+    settings.flares = False
+    assert (want != Image(settings=settings)._to_24bit(sums.copy())).mean() > 0.01   # the effect is visible
+    settings.brightness_reference = np.median
     with pytest.raises(NotImplementedError):
         r.get_display_image(settings)
 
@@ -410,7 +418,8 @@ def test_device_tone_mapping_matches_host_pipeline(low_norm):
 def test_device_tone_mapping_against_the_reference_fixture():
     """tonemap.hip against what the reference's own Image._to_24bit returned (tests/golden/
     host-io.npz, made by tools/make_golden.py host-io) for five settings: default, other gamma and
-    brightness, no floor, with earlier sums (--append), both.  The device evaluates the same
+    brightness, no floor, with earlier sums (--append), both, and two cases with the flare effect
+    (imgutils.py:121-148; filters repeated term by term).  The device evaluates the same
     binary64 pipeline with the scaling folded into one factor: at most one count of difference
     on at most 1e-4 of the values."""
     from test_host_api import tonemap_cases

@@ -433,14 +433,16 @@ def test_octree_hits_equal_brute_force_under_both_overlap_rules():
 
 def tonemap_cases():
     """(name, settings, base or None, sums, expected uint8 image) of tests/golden/host-io.npz: what
-    the reference's Image._to_24bit (/root/reference/imgutils.py:60-80) returned."""
+    the reference's Image._to_24bit (/root/reference/imgutils.py:60-80, with imgutils.flares :121-148
+    in the flare cases) returned."""
     import os
     from conftest import GOLDEN_DIR
     from raytracer_amd.imgutils import ColorEncodingSettings
     fx = np.load(os.path.join(GOLDEN_DIR, 'host-io.npz'))
     for name in fx['tonemap_cases']:
-        gamma, brightness, floor, with_base = fx['tonemap_%s_settings' % name]
+        gamma, brightness, floor, with_base, with_flares = fx['tonemap_%s_settings' % name]
         settings = ColorEncodingSettings()
+        settings.flares = bool(with_flares)
         settings.gamma, settings.brightness = float(gamma), float(brightness)
         settings.low_normalization = np.min if floor else None
         yield (str(name), settings, fx['tonemap_base'] if with_base else None, fx['tonemap_sums'],
@@ -455,7 +457,7 @@ def test_host_tone_mapping_equals_the_reference():
         assert got.dtype == np.uint8 and np.array_equal(got, want), name
         assert want.std() > 10 and (want == 255).any()
         seen += 1
-    assert seen == 5
+    assert seen == 7
 
 
 def _on_surface(tracer, point, normal, tol=1e-9):

@@ -491,7 +491,8 @@ def mesh_file_texts(rng):
 def make_host_io_fixture(seed=5):
     """Rows f2 / f3 of SURVEY section 8: the reference's own mesh readers and tone mapper run on
     generated inputs (mesh_formats.read_off / read_zipper / remove_duplicate_faces,
-    imgutils.Image._to_24bit without the flare effect).  The fixture keeps the inputs (file texts
+    imgutils.Image._to_24bit without and with the flare effect, imgutils.flares by scipy.ndimage
+    as installed here).  The fixture keeps the inputs (file texts
     written by this script, image sums) and what the reference returned."""
     import_reference()
     import io
@@ -526,7 +527,8 @@ def make_host_io_fixture(seed=5):
     fx['tonemap_base'] = base
     cases = [('default', {}, False), ('gamma16_dim', {'gamma': 1.6, 'brightness': 0.3}, False),
              ('no_floor', {'low_normalization': None}, False), ('appended', {}, True),
-             ('appended_no_floor', {'low_normalization': None, 'gamma': 2.2}, True)]
+             ('appended_no_floor', {'low_normalization': None, 'gamma': 2.2}, True),
+             ('flares', {'flares': True}, False), ('flares_appended', {'flares': True, 'gamma': 1.6}, True)]
     for name, changes, with_base in cases:
         settings = ref_img.ColorEncodingSettings()
         for key, value in changes.items():
@@ -535,7 +537,8 @@ def make_host_io_fixture(seed=5):
         fx['tonemap_%s_rgb' % name] = image._to_24bit(sums.astype(np.float64))
         fx['tonemap_%s_settings' % name] = np.array([settings.gamma, settings.brightness,
                                                      0.0 if settings.low_normalization is None else 1.0,
-                                                     1.0 if with_base else 0.0])
+                                                     1.0 if with_base else 0.0,
+                                                     1.0 if settings.flares else 0.0])
     fx['tonemap_cases'] = np.array([c[0] for c in cases])
     return fx
 
