@@ -37,6 +37,8 @@ def main():
     ap.add_argument('--rng', choices=['tape', 'philox'], default='tape',
                     help="tape: the reference's random numbers, shared by all pixels of a pass; "
                          "philox: every pixel draws its own (less correlated noise)")
+    ap.add_argument('--light-samples', type=int, default=1,
+                    help="points of the segment's light per next-event estimate (1 = the reference's estimator)")
     ap.add_argument('--gpus', type=int, default=1, help='GPUs of this node to share the render')
     ap.add_argument('--partition', choices=['passes', 'tiles'], default='passes',
                     help='passes: GPU g renders passes g, g+N, ... (one all-reduce per refresh); '
@@ -79,7 +81,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         args.device = local_rank
     renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device, rng_mode=args.rng,
-                                      **shard.renderer_arguments())
+                                      light_samples=args.light_samples, **shard.renderer_arguments())
     shard.configure(renderer)
     if scene.samples_per_pixel >= 64:
         renderer.tune_occupancy(passes=8)       # pays off for long renders only

@@ -701,7 +701,34 @@ typedef struct {
     vec3 light_point; float light_area;
     vec3 light_normal; float min_light_sampling_distance;
     vec3 light_center; int light_id;
+    /* further points of the same light (light_samples > 1; no counterpart in the reference) */
+    const float *more_lights;           /* tape: (point, normal) float4 pairs behind the record */
+    const orc_rng *rng;                 /* per-pixel numbers: the stream to draw them from */
+    unsigned pixel, pass, seg;
+    int light_index;
 } bounce_sample;
+
+/* point i >= 1 of the segment's light: from the tape, or block 2 + i of the pixel's stream */
+static void extra_light_point(const bounce_sample *B, int i, vec3 *point, vec3 *normal) {
+    if (!B->rng) {
+        *point = v3p(B->more_lights + 8 * (i - 1));
+        *normal = v3p(B->more_lights + 8 * (i - 1) + 4);
+        return;
+    }
+    float dir[3], u[3];
+    const float *L = B->rng->lights + 8 * B->light_index;
+    clr_draw_light_extra(B->rng->seed_lo, B->rng->seed_hi, B->pixel, B->pass, B->seg, (unsigned)i, dir, u);
+    *normal = v3(dir[0], dir[1], dir[2]);
+    *point = v3(L[0] + dir[0] * L[3], L[1] + dir[1] * L[3], L[2] + dir[2] * L[3]);
+    if (!(L[3] > 0.0f)) {
+        int offset;
+        float p[3], nrm[3];
+        memcpy(&offset, L + 7, 4);
+        clr_box_light_point(B->rng->lights + offset, u[2], u[0], u[1], p, nrm);
+        *point = v3(p[0], p[1], p[2]);
+        *normal = v3(nrm[0], nrm[1], nrm[2]);
+    }
+}
 
 typedef struct { const orc_scene *sc; const float *row; int stride; } material_view;
 
@@ -857,21 +884,34 @@ static int shade(const orc_scene *sc, const material_view *m, path_state *s, vec
             if (sc->bidirectional && B->light_id > 0) {
                 FL(1);
                 if (length3(sub3(s->pos, B->light_center)) > B->min_light_sampling_distance) {
-                    vec3 shadow_ray = sub3(B->light_point, s->pos);
+                    const int k_points = sc->light_samples > 1 ? sc->light_samples : 1;
+                    vec3 estimate = v3(0.0f, 0.0f, 0.0f);
                     s->suppress_emission = B->light_id;
-                    FL(2);
-                    if (dot3(shadow_ray, n) > 0 && dot3(shadow_ray, B->light_normal) < 0) {
-                        const float shadow_dist = length3(shadow_ray);
-                        shadow_ray = normalize3(shadow_ray);
-                        const float geom = dot3(n, shadow_ray) / PI_F
-                            * dot3(neg3(shadow_ray), B->light_normal) / (shadow_dist * shadow_dist);
-                        FL(4);
-                        vec3 c = to_rgb(sc, mul3(lscale3(geom, s->ray_color), pipeline_color), cmask);
-                        c = mul3(c, mat_color(m, M_EMISSION, B->light_id));
-                        c = scale3(c, shadow_mask);
-                        c = scale3(c, B->light_area);
-                        *img = add3(*img, c);
+                    for (int i = 0; i < k_points; ++i) {
+                        vec3 light_point = B->light_point, light_normal = B->light_normal;
+                        if (i > 0) extra_light_point(B, i, &light_point, &light_normal);
+                        vec3 shadow_ray = sub3(light_point, s->pos);
+                        FL(2);
+                        if (dot3(shadow_ray, n) > 0 && dot3(shadow_ray, light_normal) < 0) {
+                            const float mask = i == 0 ? shadow_mask
+                                : light_visibility(sc, s->pos, n, s->whichobject, s->which_subobject, s->inside,
+                                                   1, light_point, B->light_id);
+                            const float shadow_dist = length3(shadow_ray);
+                            shadow_ray = normalize3(shadow_ray);
+                            const float geom = dot3(n, shadow_ray) / PI_F
+                                * dot3(neg3(shadow_ray), light_normal) / (shadow_dist * shadow_dist);
+                            FL(4);
+                            vec3 c = to_rgb(sc, mul3(lscale3(geom, s->ray_color), pipeline_color), cmask);
+                            c = mul3(c, mat_color(m, M_EMISSION, B->light_id));
+                            c = scale3(c, mask);
+                            c = scale3(c, B->light_area);
+                            /* the reference's single point goes to the image as it is; several are
+                             * summed first and their mean is one addend */
+                            if (k_points == 1) *img = add3(*img, c);
+                            else estimate = add3(estimate, c);
+                        }
                     }
+                    if (k_points > 1) *img = add3(*img, scale3(estimate, (float)(1.0 / k_points)));
                 }
                 else if (s->diffusions_left == 0) {
                     s->diffusions_left = 1;
@@ -916,6 +956,7 @@ static bounce_sample load_bounce(const float *rec) {
     B.light_point = v3p(rec + 8); B.light_area = rec[11];
     B.light_normal = v3p(rec + 12); B.min_light_sampling_distance = rec[15];
     B.light_center = v3p(rec + 16); memcpy(&B.light_id, rec + 19, 4);
+    B.more_lights = rec + 4 * ORC_BOUNCE_RECORD; B.rng = 0; B.pixel = B.pass = B.seg = 0; B.light_index = 0;
     return B;
 }
 
@@ -929,9 +970,11 @@ static bounce_sample draw_bounce(const orc_rng *g, unsigned pixel, unsigned pass
     B.light_point = v3(0.0f, 0.0f, 0.0f); B.light_area = 0.0f;
     B.light_normal = v3(0.0f, 0.0f, 0.0f); B.min_light_sampling_distance = 0.0f;
     B.light_center = v3(0.0f, 0.0f, 0.0f); B.light_id = 0;
+    B.more_lights = 0; B.rng = g; B.pixel = pixel; B.pass = pass; B.seg = seg; B.light_index = 0;
     if (g->n_lights > 0) {
         int idx = (int)(d.light_u * (float)g->n_lights);
         if (idx > g->n_lights - 1) idx = g->n_lights - 1;
+        B.light_index = idx;
         const float *L = g->lights + 8 * idx;
         B.light_normal = v3(d.light_dir[0], d.light_dir[1], d.light_dir[2]);
         B.light_point = v3(L[0] + d.light_dir[0] * L[3], L[1] + d.light_dir[1] * L[3], L[2] + d.light_dir[2] * L[3]);
@@ -1021,6 +1064,7 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
         orc_mesh_bytes = 0.0;
 #endif
         const vec3 base_ray = v3p(cam + 4 * k);
+        const int bounce_record = ORC_BOUNCE_RECORD + 2 * ((sc->light_samples > 1 ? sc->light_samples : 1) - 1);
         vec3 acc = v3p(img + 4 * k);
         for (int pass = 0; pass < n_passes; ++pass) {
             const float *prec = pass_tape + (size_t)pass * ORC_PASS_RECORD * 4;
@@ -1033,7 +1077,7 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
                 const bounce_sample B = rng
                     ? draw_bounce(rng, (unsigned)(rng->first_ray + k), (unsigned)(rng->first_pass + pass * (rng->pass_stride > 0 ? rng->pass_stride : 1)), (unsigned)b,
                                   b == sc->max_bounces - 1)
-                    : load_bounce(bounce_tape + ((size_t)pass * sc->max_bounces + b) * ORC_BOUNCE_RECORD * 4);
+                    : load_bounce(bounce_tape + ((size_t)pass * sc->max_bounces + b) * bounce_record * 4);
                 float *d = dbg ? dbg + ((size_t)b * n_pixels + k) * ORC_DEBUG_RECORD * 4 : 0;
                 if (!segment(sc, &m, &s, &B, b == sc->max_bounces - 1, cmask, &acc, d)) break;
             }

@@ -65,6 +65,7 @@ typedef struct orc_scene {
     int bidirectional;
     float min_russian_prob;             /* 0 = roulette off */
     float max_ray_length;
+    int light_samples;                  /* points of the segment's light per next-event estimate; 0 = 1 */
 } orc_scene;
 
 /* per-pixel random numbers (hip_templates/clr_rng.inl) instead of the bounce tape */
@@ -78,7 +79,7 @@ typedef struct orc_rng {
 } orc_rng;
 
 #define ORC_PASS_RECORD 6
-#define ORC_BOUNCE_RECORD 5
+#define ORC_BOUNCE_RECORD 5             /* + 2 per further light point (light_samples > 1) */
 #define ORC_DEBUG_RECORD 6
 
 /* Adds n_passes sample passes to img (n_pixels x float4, running sums).  Tapes as in

@@ -49,7 +49,8 @@ class Scene(ctypes.Structure):
                 ('material_scalars', ctypes.POINTER(ctypes.c_float)),
                 ('max_bounces', ctypes.c_int), ('min_bounces', ctypes.c_int),
                 ('root_object_id', ctypes.c_int), ('bidirectional', ctypes.c_int),
-                ('min_russian_prob', ctypes.c_float), ('max_ray_length', ctypes.c_float)]
+                ('min_russian_prob', ctypes.c_float), ('max_ray_length', ctypes.c_float),
+                ('light_samples', ctypes.c_int)]
 
 
 def build(force=False):
@@ -218,6 +219,7 @@ class OracleScene:
             sc.material_colors = _fptr(self.colors)
             sc.material_scalars = _fptr(self.scalars)
         sc.max_bounces = scene.max_bounces
+        sc.light_samples = getattr(renderer, 'light_samples', 1)
         sc.min_bounces = scene.min_bounces
         sc.root_object_id = renderer.root_object_id
         sc.bidirectional = int(renderer.bidirectional)

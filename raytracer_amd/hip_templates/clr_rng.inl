@@ -121,6 +121,16 @@ CLR_MATH_FN void clr_draw_light(unsigned seed_lo, unsigned seed_hi, unsigned pix
     clr_sphere_direction(uniforms[0], uniforms[1], light_dir);
 }
 
+/* Further points of the same light (light_samples > 1): point `sample` >= 1 of a segment takes block
+ * 2 + sample of the pixel's stream; its first word (the choice of the light) is not used. */
+CLR_MATH_FN void clr_draw_light_extra(unsigned seed_lo, unsigned seed_hi, unsigned pixel, unsigned pass,
+                                      unsigned segment, unsigned sample, float light_dir[3], float uniforms[3]) {
+    unsigned r[4];
+    clr_philox4x32(pixel, pass, segment, 2u + sample, seed_lo, seed_hi, r);
+    uniforms[0] = clr_u01(r[1]); uniforms[1] = clr_u01(r[2]); uniforms[2] = clr_u01(r[3]);
+    clr_sphere_direction(uniforms[0], uniforms[1], light_dir);
+}
+
 /* Point and outward normal on a box light (Parallelepiped.random_surface_point_and_normal).
  * faces: 6 records of 16 floats = (start corner, share of the total area up to and including this
  * face), (edge u, 0), (edge v, 0), (outward unit normal, 0); the face is picked by area. */

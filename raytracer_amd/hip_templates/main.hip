@@ -53,6 +53,28 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g);
 ### endif
 
+### if renderer.light_samples > 1 and renderer.rng_mode == 'philox'
+// point `sample` >= 1 on light `idx` of clr_lights from the pixel's own stream (clr_draw_bounce
+// below draws point 0 the same way)
+CLR_FN void clr_draw_light_point(const uint seed_lo, const uint seed_hi, const uint pixel, const uint pass,
+                                 const uint segment, const int sample, const int idx, vec3 &point, vec3 &normal) {
+    float light_dir[3], light_uniforms[3];
+    clr_draw_light_extra(seed_lo, seed_hi, pixel, pass, segment, (uint)sample, light_dir, light_uniforms);
+    const float4 L0 = clr_lights[2*idx], L1 = clr_lights[2*idx + 1];
+    normal = make_vec3(light_dir[0], light_dir[1], light_dir[2]);
+    point = make_vec3(L0.x + light_dir[0] * L0.w, L0.y + light_dir[1] * L0.w, L0.z + light_dir[2] * L0.w);
+    ### if renderer.has_box_lights
+    if (!(L0.w > 0.0f)) {
+        float p[3], nrm[3];
+        clr_box_light_point((const float *)clr_lights + __float_as_int(L1.w), light_uniforms[2],
+                            light_uniforms[0], light_uniforms[1], p, nrm);
+        point = make_vec3(p[0], p[1], p[2]);
+        normal = make_vec3(nrm[0], nrm[1], nrm[2]);
+    }
+    ### endif
+}
+### endif
+
 {% include 'shader.hip' %}
 
 // ---- shape functions
@@ -73,7 +95,7 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
 #define CLR_MAX_RAY_LENGTH {{ renderer.scene.max_ray_length|float }}f
 #define CLR_N_OBJECTS {{ n_objects }}
 #define CLR_PASS_STRIDE 6
-#define CLR_BOUNCE_STRIDE 5
+#define CLR_BOUNCE_STRIDE {{ renderer.bounce_record }}
 #define CLR_MATERIAL_ROW {{ 10*(n_objects+1) }}
 
 // closest hit over every object of the scene (renderer.py:338-344)
@@ -179,6 +201,9 @@ CLR_FN BounceSample clr_load_bounce(const float4 * __restrict__ rec) {
     B.light_point = make_vec3(c); B.light_area = c.w;
     B.light_normal = make_vec3(d); B.min_light_sampling_distance = d.w;
     B.light_center = make_vec3(e); B.light_id = __float_as_int(e.w);
+### if renderer.light_samples > 1 and renderer.rng_mode != 'philox'
+    B.more_lights = rec + 5;
+### endif
     return B;
 }
 
@@ -195,6 +220,9 @@ CLR_FN BounceSample clr_draw_bounce(const uint seed_lo, const uint seed_hi, cons
     B.light_point = make_vec3(0.0f, 0.0f, 0.0f); B.light_area = 0.0f;
     B.light_normal = make_vec3(0.0f, 0.0f, 0.0f); B.min_light_sampling_distance = 0.0f;
     B.light_center = make_vec3(0.0f, 0.0f, 0.0f); B.light_id = 0;
+    ### if renderer.light_samples > 1
+    B.light_index = 0;
+    ### endif
     ### if renderer.n_lights
     if (with_light) {
         float light_u, light_dir[3], light_uniforms[3];
@@ -217,6 +245,9 @@ CLR_FN BounceSample clr_draw_bounce(const uint seed_lo, const uint seed_hi, cons
         B.min_light_sampling_distance = L1.y;
         B.light_center = make_vec3(L0);
         B.light_id = __float_as_int(L1.z);
+        ### if renderer.light_samples > 1
+        B.light_index = idx;
+        ### endif
     }
     ### endif
     return B;

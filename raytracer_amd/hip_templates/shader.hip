@@ -97,6 +97,21 @@ struct BounceSample {                    // one record of the random tape (SURVE
     vec3 light_point; float light_area;
     vec3 light_normal; float min_light_sampling_distance;
     vec3 light_center; int light_id;     // 0 on the last segment / without lights
+### if renderer.light_samples > 1
+    // further points of the same light (light_samples > 1): i = 1 .. light_samples - 1
+    ### if renderer.rng_mode == 'philox'
+    int light_index;                     // row of clr_lights
+    CLR_FN_MEMBER void light_sample(const int i, vec3 &point, vec3 &normal) const {
+        clr_draw_light_point(seed_lo, seed_hi, pixel, pass, segment, i, light_index, point, normal);
+    }
+    ### else
+    const float4 *more_lights;           // (point, normal) pairs behind the record in the tape
+    CLR_FN_MEMBER void light_sample(const int i, vec3 &point, vec3 &normal) const {
+        point = make_vec3(more_lights[2*i - 2]);
+        normal = make_vec3(more_lights[2*i - 1]);
+    }
+    ### endif
+### endif
 };
 
 // Runs the stage pipeline for one path segment that ended at s.pos (surface s.whichobject,
@@ -292,21 +307,47 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
             if (B.light_id > 0) {
                 // next-event estimation towards the light point of this segment
                 if (length(s.pos - B.light_center) > B.min_light_sampling_distance) {
-                    vec3 shadow_ray = B.light_point - s.pos;
                     s.suppress_emission = B.light_id;
-                    if (dot(shadow_ray, n) > 0 && dot(shadow_ray, B.light_normal) < 0) {
-                        // diffusions_left was at least 1 before this stage took one
-                        const float shadow_mask = !lazy_visibility ? eager_shadow_mask :
-                            clr_light_visibility(s.pos, n, s.whichobject, s.which_subobject, s.inside, 1,
-                                                 B.light_point, B.light_id, vector_data, integer_data, clr_g);
-                        const float shadow_dist = length(shadow_ray);
-                        shadow_ray = fast_normalize(shadow_ray);
-                        const float geom = dot(n, shadow_ray) / CLR_PI_F
-                            * dot(-shadow_ray, B.light_normal) / (shadow_dist*shadow_dist);
-                        img += color_to_rgb(geom * s.ray_color * pipeline_color, cmask)
-                            * color_to_rgb(m_light_emission, make_vec3(1.0f, 1.0f, 1.0f))
-                            * shadow_mask * B.light_area;
+### if renderer.light_samples > 1
+                    // mean over light_samples points of the light: the terms are summed first and
+                    // reach the image as one addend (the pass-split log holds one per stage)
+                    vec3 estimate = make_vec3(0.0f, 0.0f, 0.0f);
+                    #pragma unroll 1
+                    for (int light_i = 0; light_i < {{ renderer.light_samples }}; ++light_i) {
+                        vec3 light_point = B.light_point, light_normal = B.light_normal;
+                        if (light_i > 0) B.light_sample(light_i, light_point, light_normal);
+### else
+                    {
+                        const vec3 light_point = B.light_point, light_normal = B.light_normal;
+### endif
+                        vec3 shadow_ray = light_point - s.pos;
+                        if (dot(shadow_ray, n) > 0 && dot(shadow_ray, light_normal) < 0) {
+                            // diffusions_left was at least 1 before this stage took one
+### if renderer.light_samples > 1
+                            const float shadow_mask = (!lazy_visibility && light_i == 0) ? eager_shadow_mask :
+### else
+                            const float shadow_mask = !lazy_visibility ? eager_shadow_mask :
+### endif
+                                clr_light_visibility(s.pos, n, s.whichobject, s.which_subobject, s.inside, 1,
+                                                     light_point, B.light_id, vector_data, integer_data, clr_g);
+                            const float shadow_dist = length(shadow_ray);
+                            shadow_ray = fast_normalize(shadow_ray);
+                            const float geom = dot(n, shadow_ray) / CLR_PI_F
+                                * dot(-shadow_ray, light_normal) / (shadow_dist*shadow_dist);
+### if renderer.light_samples > 1
+                            estimate += color_to_rgb(geom * s.ray_color * pipeline_color, cmask)
+                                * color_to_rgb(m_light_emission, make_vec3(1.0f, 1.0f, 1.0f))
+                                * shadow_mask * B.light_area;
+### else
+                            img += color_to_rgb(geom * s.ray_color * pipeline_color, cmask)
+                                * color_to_rgb(m_light_emission, make_vec3(1.0f, 1.0f, 1.0f))
+                                * shadow_mask * B.light_area;
+### endif
+                        }
                     }
+### if renderer.light_samples > 1
+                    img += estimate * {{ renderer.light_weight_literal }};
+### endif
                 }
                 else if (s.diffusions_left == 0) {
                     // too close to the light for a stable estimate: allow one more bounce

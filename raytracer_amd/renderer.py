@@ -20,7 +20,7 @@ from .hip_compiler import Compiler, PARITY_OPTIONS
 from .accelerator import Accelerator, RenderArgs
 
 PASS_RECORD = 6      # float4 per pass in the tape
-BOUNCE_RECORD = 5    # float4 per path segment in the tape
+BOUNCE_RECORD = 5    # float4 per path segment in the tape (+ 2 per further light point, light_samples > 1)
 DEBUG_RECORD = 6     # float4 per (segment, pixel) in the debug dump
 
 
@@ -74,8 +74,16 @@ class Renderer:
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
                  min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None,
-                 regenerate=None):
+                 regenerate=None, light_samples=1):
         self.scene = scene
+        # next-event estimation with k points of the segment's light instead of one (no
+        # counterpart in the reference, k = 1 is its estimator).  The light is still picked once per
+        # segment; its contribution is the mean over the k points, each with its own visibility test.
+        if not 1 <= int(light_samples) <= 16:
+            raise ValueError("light_samples must be in 1..16")
+        self.light_samples = int(light_samples)
+        self.bounce_record = BOUNCE_RECORD + 2 * (self.light_samples - 1)
+        self.light_weight_literal = float(np.float32(1.0 / self.light_samples)).hex() + 'f'
         # tile partitioning: (first ray, count) in ray order; a contiguous range of ray
         # indices is a set of 4-pixel-wide column blocks of the frame (get_image_order)
         self.ray_range = ray_range
@@ -366,7 +374,7 @@ class Renderer:
         max_bounces = scene.max_bounces
         passes = np.zeros((n_passes, PASS_RECORD, 4), dtype=np.float32)
         per_pixel = self.rng_mode == 'philox'        # then only the per-pass part is drawn here
-        bounces = None if per_pixel else np.zeros((n_passes, max_bounces, BOUNCE_RECORD, 4), dtype=np.float32)
+        bounces = None if per_pixel else np.zeros((n_passes, max_bounces, self.bounce_record, 4), dtype=np.float32)
         rows = None
         if not self.shader.rgb:
             rows = np.zeros((n_passes, self.shader.host_mat_y.shape[0]), dtype=np.float32)
@@ -389,6 +397,11 @@ class Renderer:
                     rec[3, 0:3], rec[3, 3] = normal, min_dist
                     rec[4, 0:3] = center
                     rec[4, 3:4] = np.array([0 if is_last else light_id0 + 1], dtype=np.int32).view(np.float32)
+                    tracer = scene.objects[light_id0].tracer
+                    for extra in range(self.light_samples - 1):
+                        point, normal = tracer.random_surface_point_and_normal(self.rng)
+                        rec[BOUNCE_RECORD + 2 * extra, 0:3] = point
+                        rec[BOUNCE_RECORD + 2 * extra + 1, 0:3] = normal
                 if scene.quasirandom and b == 1:
                     rec[0, 0:3] = self.qdirs[first_pass + j, :]
                 else:
