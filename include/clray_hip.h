@@ -88,6 +88,16 @@ int clr_buffer_free(clr_ctx *ctx, void *device_ptr);
 int clr_buffer_upload(clr_ctx *ctx, void *device_ptr, const void *host, size_t bytes, void *stream);
 int clr_buffer_download(clr_ctx *ctx, void *host, const void *device_ptr, size_t bytes, void *stream);
 int clr_buffer_fill32(clr_ctx *ctx, void *device_ptr, uint32_t value, size_t count, void *stream);
+/* replaces Accelerator.device_memcpy (accelerator.py:224-229): device-to-device copy of `bytes` */
+int clr_buffer_copy(clr_ctx *ctx, void *dest, const void *src, size_t bytes, void *stream);
+
+/* ---- replaces Accelerator.find_non_negative (accelerator.py:196-222, pyopencl GenericScanKernel):
+ * stable compaction of 32-bit integers.  Writes the elements of in[0..n) that are >= 0 to
+ * out[0..count) in their order and returns count in *count (host memory; the call waits for the
+ * result like the reference's).  out must hold n elements in the worst case and must not overlap
+ * in.  Three launches: per-tile counts (4096 elements a tile), scan of the counts, scatter; the
+ * counts live in a work buffer the context keeps and grows on demand (4 B per tile). */
+int clr_find_non_negative(clr_ctx *ctx, const int32_t *in, int32_t *out, size_t n, int *count, void *stream);
 
 /* ---- generic launch: replaces Accelerator.call (accelerator.py:63-89) for step-wise kernels.
  * args[i] points to the i-th kernel argument.  If elapsed_ms is not NULL the launch is

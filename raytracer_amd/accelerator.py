@@ -93,6 +93,8 @@ def load_library():
         'clr_buffer_upload': (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
         'clr_buffer_download': (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
         'clr_buffer_fill32': (ci, [vp, vp, ctypes.c_uint32, ctypes.c_size_t, vp]),
+        'clr_buffer_copy': (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
+        'clr_find_non_negative': (ci, [vp, vp, vp, ctypes.c_size_t, P(ci), vp]),
         'clr_launch': (ci, [vp, cp, P(ctypes.c_uint), P(ctypes.c_uint), ci, P(vp), vp,
                             P(ctypes.c_float)]),
         'clr_render_passes': (ci, [vp, P(RenderArgs), vp, P(ctypes.c_float)]),
@@ -450,6 +452,32 @@ class Accelerator:
             dest.set(np.asarray(src).reshape(dest.shape) if np.size(src) == int(np.prod(dest.shape)) else src)
         else:
             np.copyto(dest, src.get())
+
+    def device_memcpy(self, dest, src, n=None):
+        """Device-to-device copy of `n` 32-bit values, or of all of `src` (reference accelerator.py:224-229)."""
+        nbytes = src.nbytes if n is None else int(n) * 4
+        if nbytes > dest.nbytes or nbytes > src.nbytes:
+            raise ValueError("device_memcpy: %d bytes do not fit" % nbytes)
+        _check(self.lib.clr_buffer_copy(self.ctx, ctypes.c_void_p(dest.ptr), ctypes.c_void_p(src.ptr),
+                                        ctypes.c_size_t(nbytes), None))
+        self.finish()
+
+    def find_non_negative(self, in_array, out_array, n):
+        """Stable compaction on the device: the first `n` elements of the int32 array `in_array` that
+        are >= 0 go to the front of `out_array` in their order; returns how many (reference
+        accelerator.py:196-222, there a pyopencl scan kernel).  The fused render kernel does not need
+        it; it is here for step-wise callers of the reference's interface."""
+        if in_array.dtype != np.int32 or out_array.dtype != np.int32:
+            raise TypeError("find_non_negative works on int32 arrays")
+        n = int(n)
+        if n * 4 > in_array.nbytes or n * 4 > out_array.nbytes:
+            raise ValueError("find_non_negative: n exceeds an array")
+        t0 = time.time()
+        count = ctypes.c_int(0)
+        _check(self.lib.clr_find_non_negative(self.ctx, ctypes.c_void_p(in_array.ptr), ctypes.c_void_p(out_array.ptr),
+                                              ctypes.c_size_t(n), ctypes.byref(count), None))
+        self._record('find_non_negative', 0.0, time.time() - t0)
+        return count.value
 
     def to_device(self, cpuarray):
         return DeviceArray(self, cpuarray.shape, cpuarray.dtype).set(cpuarray)

@@ -54,10 +54,91 @@ int resolve_scratch(int device) {
 
 }  // namespace
 
+// ---- stable compaction of the non-negative elements (clr_find_non_negative)
+// A tile = 16 rounds of 256 consecutive elements; within a round the position of an element among
+// the kept ones is its rank in its wave's ballot plus the kept counts of the waves before it.
+namespace {
+
+constexpr int kCompactBlock = 256, kCompactRounds = 16, kCompactTile = kCompactBlock * kCompactRounds;
+constexpr int kCompactWaves = kCompactBlock / 64;
+
+__global__ void __launch_bounds__(kCompactBlock)
+compact_count(const int * __restrict__ in, const size_t n, unsigned * __restrict__ tile_count) {
+    __shared__ unsigned wave_total[kCompactWaves];
+    const size_t base = (size_t)blockIdx.x * kCompactTile;
+    unsigned kept = 0;
+    for (int r = 0; r < kCompactRounds; ++r) {
+        const size_t i = base + (size_t)r * kCompactBlock + threadIdx.x;
+        kept += __popcll(__ballot(i < n && in[i] >= 0));      // the same number in every lane of the wave
+    }
+    if ((threadIdx.x & 63) == 0) wave_total[threadIdx.x >> 6] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned sum = 0;
+        for (int w = 0; w < kCompactWaves; ++w) sum += wave_total[w];
+        tile_count[blockIdx.x] = sum;
+    }
+}
+
+// one block: counts -> exclusive offsets in place, total behind them
+__global__ void __launch_bounds__(1024)
+compact_scan(unsigned * __restrict__ tile_count, const size_t n_tiles) {
+    __shared__ unsigned s[1024];
+    __shared__ unsigned carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (size_t first = 0; first < n_tiles; first += 1024) {
+        const size_t i = first + threadIdx.x;
+        const unsigned own = i < n_tiles ? tile_count[i] : 0;
+        s[threadIdx.x] = own;
+        __syncthreads();
+        for (int step = 1; step < 1024; step <<= 1) {
+            const unsigned add = (int)threadIdx.x >= step ? s[threadIdx.x - step] : 0;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_count[i] = carry + s[threadIdx.x] - own;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_count[n_tiles] = carry;
+}
+
+__global__ void __launch_bounds__(kCompactBlock)
+compact_scatter(const int * __restrict__ in, int * __restrict__ out, const size_t n,
+                const unsigned * __restrict__ tile_offset) {
+    __shared__ unsigned wave_total[2][kCompactWaves];
+    const size_t base = (size_t)blockIdx.x * kCompactTile;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    size_t running = tile_offset[blockIdx.x];
+    for (int r = 0; r < kCompactRounds; ++r) {
+        const size_t i = base + (size_t)r * kCompactBlock + threadIdx.x;
+        const int value = i < n ? in[i] : -1;
+        const bool keep = value >= 0;
+        const unsigned long long votes = __ballot(keep);
+        if (lane == 0) wave_total[r & 1][wave] = __popcll(votes);
+        __syncthreads();                    // one barrier a round: the two halves of wave_total alternate
+        unsigned before = 0, all = 0;
+        for (int w = 0; w < kCompactWaves; ++w) {
+            const unsigned t = wave_total[r & 1][w];
+            before += w < wave ? t : 0;
+            all += t;
+        }
+        if (keep) out[running + before + __popcll(votes & ((1ull << lane) - 1ull))] = value;
+        running += all;
+    }
+}
+
+}  // namespace
+
 struct clr_ctx {
     int device;
     hipEvent_t ev_start, ev_stop;         // around one timed launch
     hipEvent_t timer_start, timer_stop;   // clr_timer_begin / clr_timer_end
+    unsigned *compact_work;               // clr_find_non_negative: per-tile counts / offsets, then the total
+    size_t compact_tiles;                 // tiles the work buffer has room for
 };
 
 struct clr_program {
@@ -138,6 +219,8 @@ int clr_ctx_create(int device_index, clr_ctx **out) {
     if (int rc = resolve_scratch(device_index)) return rc;
     clr_ctx *ctx = new clr_ctx;
     ctx->device = device_index;
+    ctx->compact_work = nullptr;
+    ctx->compact_tiles = 0;
     if (int rc = check(hipEventCreate(&ctx->ev_start), "hipEventCreate")) { delete ctx; return rc; }
     if (int rc = check(hipEventCreate(&ctx->ev_stop), "hipEventCreate")) { delete ctx; return rc; }
     if (int rc = check(hipEventCreate(&ctx->timer_start), "hipEventCreate")) { delete ctx; return rc; }
@@ -153,6 +236,7 @@ int clr_ctx_destroy(clr_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev_stop);
     (void)hipEventDestroy(ctx->timer_start);
     (void)hipEventDestroy(ctx->timer_stop);
+    if (ctx->compact_work) (void)hipFree(ctx->compact_work);
     delete ctx;
     return 0;
 }
@@ -352,6 +436,41 @@ int clr_buffer_download(clr_ctx *ctx, void *host, const void *device_ptr, size_t
 int clr_buffer_fill32(clr_ctx *ctx, void *device_ptr, uint32_t value, size_t count, void *stream) {
     if (int rc = set_device(ctx)) return rc;
     CLR_TRY(hipMemsetD32Async((hipDeviceptr_t)device_ptr, (int)value, count, (hipStream_t)stream));
+    return 0;
+}
+
+int clr_buffer_copy(clr_ctx *ctx, void *dest, const void *src, size_t bytes, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!bytes) return 0;
+    if (!dest || !src) return fail("clr_buffer_copy: null buffer");
+    CLR_TRY(hipMemcpyDtoDAsync((hipDeviceptr_t)dest, (hipDeviceptr_t)src, bytes, (hipStream_t)stream));
+    return 0;
+}
+
+int clr_find_non_negative(clr_ctx *ctx, const int32_t *in, int32_t *out, size_t n, int *count, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!count) return fail("clr_find_non_negative: null count pointer");
+    *count = 0;
+    if (n == 0) return 0;
+    if (!in || !out) return fail("clr_find_non_negative: null buffer");
+    if (n > (size_t)0x7fffffff) return fail("clr_find_non_negative: more than 2^31 - 1 elements");
+    const size_t n_tiles = (n + kCompactTile - 1) / kCompactTile;
+    if (ctx->compact_tiles < n_tiles) {
+        if (ctx->compact_work) CLR_TRY(hipFree(ctx->compact_work));
+        ctx->compact_work = nullptr;
+        ctx->compact_tiles = 0;
+        CLR_TRY(hipMalloc((void **)&ctx->compact_work, (n_tiles + 1) * sizeof(unsigned)));
+        ctx->compact_tiles = n_tiles;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    compact_count<<<dim3((unsigned)n_tiles), dim3(kCompactBlock), 0, s>>>(in, n, ctx->compact_work);
+    compact_scan<<<dim3(1), dim3(1024), 0, s>>>(ctx->compact_work, n_tiles);
+    compact_scatter<<<dim3((unsigned)n_tiles), dim3(kCompactBlock), 0, s>>>(in, out, n, ctx->compact_work);
+    CLR_TRY(hipGetLastError());
+    unsigned total = 0;
+    CLR_TRY(hipMemcpyAsync(&total, ctx->compact_work + n_tiles, sizeof(total), hipMemcpyDeviceToHost, s));
+    CLR_TRY(hipStreamSynchronize(s));
+    *count = (int)total;
     return 0;
 }
 

@@ -736,3 +736,43 @@ def test_several_light_points_per_segment():
 
     one, eight = rendering(1, 29), rendering(8, 30)
     assert abs(eight.mean() - one.mean()) < 0.02 * one.mean(), (eight.mean(), one.mean())
+
+
+def test_find_non_negative_and_device_memcpy():
+    """Accelerator.find_non_negative (reference accelerator.py:196-222: the stable compaction behind
+    the culler) and device_memcpy (:224-229) through the C ABI, against numpy: sizes around the tile
+    (4096) and block (256) boundaries, all kept, none kept, a million elements, and the same
+    context reused with a smaller input after a larger one."""
+    from raytracer_amd.accelerator import Accelerator
+    acc = Accelerator(0)
+    rng = np.random.RandomState(8)
+    for n in (1, 63, 64, 255, 256, 257, 4095, 4096, 4097, 12289, 1 << 20, (1 << 20) + 3, 1000):
+        for keep in (0.5, 0.02, 1.0, 0.0):
+            values = rng.randint(0, 1 << 30, size=n).astype(np.int32)
+            values[rng.random_sample(n) >= keep] = -1
+            if keep == 0.5:
+                values[rng.randint(n)] = 0                      # zero counts as non-negative
+            src = acc.to_device(values)
+            dst = acc.new_array((n,), np.int32)
+            dst.fill(-7)
+            count = acc.find_non_negative(src, dst, n)
+            want = values[values >= 0]
+            assert count == want.size, (n, keep, count, want.size)
+            got = dst.get()
+            assert np.array_equal(got[:count], want), (n, keep)
+            assert (got[count:] == -7).all()                    # nothing written behind the result
+    # only the first n elements take part
+    values = np.arange(-5, 5000, dtype=np.int32)
+    src, dst = acc.to_device(values), acc.new_array((values.size,), np.int32)
+    assert acc.find_non_negative(src, dst, 100) == 95
+    assert np.array_equal(dst.get()[:95], np.arange(0, 95))
+    assert acc.find_non_negative(src, dst, 0) == 0
+    with pytest.raises(TypeError):
+        acc.find_non_negative(acc.new_array((4,), np.float32), dst, 4)
+    # device_memcpy: whole array, or the first n 32-bit values
+    copy = acc.new_array((values.size,), np.int32)
+    copy.fill(0)
+    acc.device_memcpy(copy, src, 10)
+    assert np.array_equal(copy.get()[:10], values[:10]) and (copy.get()[10:] == 0).all()
+    acc.device_memcpy(copy, src)
+    assert np.array_equal(copy.get(), values)
