@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument('--mesh-overlap', choices=['sat', 'reference'], default='sat',
                     help="scene-mesh: rule that files faces under octree leaves (same hits either way): "
                          "'sat' triangle against box, 'reference' the reference's bounding-sphere rule")
+    ap.add_argument('--mesh-depth', type=int, default=None, help='scene-mesh: octree depth (default: by face count)')
+    ap.add_argument('--mesh-leaf', type=int, default=None, help='scene-mesh: faces per leaf before a node splits (default 8)')
     ap.add_argument('--marchers', default=None,
                     help='scene-marchers: comma-separated names of the ray-marched objects to keep (development)')
     ap.add_argument('--seed', type=int, default=0)
@@ -157,8 +159,13 @@ def main():
         path = os.path.join(ROOT, 'raytracer_amd', 'scenes', args.scene + '.py')
         if args.scene == 'scene-mesh':
             n_u, n_v = (int(v) for v in args.mesh_grid.lower().split('x'))
+            tree = {}
+            if args.mesh_depth is not None:
+                tree['max_depth'] = args.mesh_depth
+            if args.mesh_leaf is not None:
+                tree['max_faces_per_leaf'] = args.mesh_leaf
             scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout,
-                                                                       overlap=args.mesh_overlap)
+                                                                       overlap=args.mesh_overlap, **tree)
         elif args.scene == 'scene-marchers' and args.marchers is not None:
             scene = runpy.run_path(path, run_name='lib')['make_scene'](only=args.marchers.split(','))
         else:
