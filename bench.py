@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument('--mesh-overlap', choices=['sat', 'reference'], default='sat',
                     help="scene-mesh: rule that files faces under octree leaves (same hits either way): "
                          "'sat' triangle against box, 'reference' the reference's bounding-sphere rule")
+    ap.add_argument('--mesh-pooled', type=int, default=None,
+                    help='scene-mesh: 1/0 triangle tests pooled over the wave or per lane (default: the Octree class decides)')
     ap.add_argument('--mesh-depth', type=int, default=None, help='scene-mesh: octree depth (default: by face count)')
     ap.add_argument('--mesh-leaf', type=int, default=None, help='scene-mesh: faces per leaf before a node splits (default 8)')
     ap.add_argument('--marchers', default=None,
@@ -164,6 +166,8 @@ def main():
                 tree['max_depth'] = args.mesh_depth
             if args.mesh_leaf is not None:
                 tree['max_faces_per_leaf'] = args.mesh_leaf
+            if args.mesh_pooled is not None:
+                tree['pooled'] = bool(args.mesh_pooled)
             scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout,
                                                                        overlap=args.mesh_overlap, **tree)
         elif args.scene == 'scene-marchers' and args.marchers is not None:

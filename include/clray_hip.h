@@ -54,6 +54,10 @@ int clr_program_destroy(clr_program *prog);
 /* Copies `bytes` from host memory into the module-scope device variable `name`
  * (the __constant__ scene tables: parameters, data offsets, materials). */
 int clr_program_set_global(clr_program *prog, const char *name, const void *host, size_t bytes);
+/* The other direction: waits for the device and copies `bytes` of the module global `name` to
+ * host memory (no counterpart in the reference; counters that a development build of a program
+ * keeps, tools/mesh_phases.py). */
+int clr_program_get_global(clr_program *prog, const char *name, void *host, size_t bytes);
 /* Compile only (no device needed): returns the code-object size; used by the build check. */
 int clr_compile_only(const char *source, int n_options, const char **options, const char *arch,
                      size_t *code_size);

@@ -82,6 +82,7 @@ def load_library():
         'clr_program_build': (ci, [vp, cp, ci, P(cp), P(vp)]),
         'clr_program_destroy': (ci, [vp]),
         'clr_program_set_global': (ci, [vp, cp, vp, ctypes.c_size_t]),
+        'clr_program_get_global': (ci, [vp, cp, vp, ctypes.c_size_t]),
         'clr_compile_only': (ci, [cp, ci, P(cp), cp, P(ctypes.c_size_t)]),
         'clr_compile': (ci, [cp, ci, P(cp), cp, P(vp), P(ctypes.c_size_t)]),
         'clr_binary_free': (None, [vp]),
@@ -397,6 +398,13 @@ class Accelerator:
         host = np.ascontiguousarray(host)
         _check(self.lib.clr_program_set_global(self.prog, name.encode(),
                                                host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+
+    def get_global(self, name, shape, dtype):
+        """Contents of a module global of the current program (waits for the device)."""
+        host = np.zeros(shape, dtype=dtype)
+        _check(self.lib.clr_program_get_global(self.prog, name.encode(),
+                                               host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+        return host
 
     def _record(self, name, device_seconds, host_seconds):
         info = self.profiling_info.setdefault(name, {'n': 0, 't': 0.0, 'ta': 0.0})

@@ -393,6 +393,20 @@ int clr_program_set_global(clr_program *prog, const char *name, const void *host
     return 0;
 }
 
+int clr_program_get_global(clr_program *prog, const char *name, void *host, size_t bytes) {
+    if (!prog || !name || !host) return fail("null argument");
+    if (int rc = set_device(prog->ctx)) return rc;
+    hipDeviceptr_t dptr;
+    size_t size = 0;
+    CLR_TRY(hipModuleGetGlobal(&dptr, &size, prog->module, name));
+    if (bytes > size)
+        return fail(std::string("clr_program_get_global: ") + name + " holds " + std::to_string(size) +
+                    " bytes, asked to read " + std::to_string(bytes));
+    CLR_TRY(hipDeviceSynchronize());
+    CLR_TRY(hipMemcpyDtoH(host, dptr, bytes));
+    return 0;
+}
+
 int clr_kernel_info(clr_program *prog, const char *kernel, clr_kernel_info_t *out) {
     if (!prog || !kernel || !out) return fail("null argument");
     if (int rc = set_device(prog->ctx)) return rc;

@@ -3,6 +3,9 @@
     the launch schedule of renderer.py:293-433, which here runs on the device: each lane
     owns one pixel and walks its sample passes and path segments in registers. -#}
 {% include 'static.hip' %}
+### if renderer.profile_mesh_phases
+__device__ unsigned long long clr_mesh_phases[64 * 16];
+### endif
 
 // ---- scene tables, filled by the host after the module is loaded
 // clr_params, per object: declared parameters, then 4 rows of the inverse affine

@@ -134,7 +134,8 @@
     Here every step has three phases:
       A  each lane still traversing locates its leaf: (first record, count), exit distance;
       B  the (lane, triangle) pairs of the whole wave form one list (prefix sum of the counts
-         over the lanes executing this call, kept in LDS by rank) that is dealt out evenly:
+         over the lanes executing this call, taken from ballots of their bit planes and kept in
+         LDS by rank) that is dealt out evenly:
          every lane - also one that has finished its own traversal - takes list entry
          round*A + rank, finds the owner by binary search in the prefix sums, reads the owner's
          ray from LDS and tests the triangle with the arithmetic of flat_triangle_loop; a hit
@@ -156,10 +157,23 @@
         int *stack = stack_lds + threadIdx.x;
         #define STACK(level) stack[(level) * 256]
         #define POOL_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
+        ### if obj.profile_phases
+        // development build (CLR_MESH_PROFILE=1, tools/mesh_phases.py): cycles per phase, kept per
+        // lane during the call and added by one lane per wave to one of 64 copies of the counters
+        #define PHASE_CLOCK() ((long long)__builtin_readcyclecounter())
+        long long phase_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        #define PHASE_ADD(slot, value) phase_sum[slot] += (long long)(value)
+        long long phase_mark = PHASE_CLOCK();
+        #define PHASE_END(slot) { const long long now = PHASE_CLOCK(); phase_sum[slot] += now - phase_mark; phase_mark = now; }
+        ### else
+        #define PHASE_ADD(slot, value)
+        #define PHASE_END(slot)
+        ### endif
 
         const int tid = threadIdx.x, wave_base = tid & ~63;
         const unsigned long long exec_mask = __ballot(1);
-        const int rank = __popcll(exec_mask & ((1ull << (tid & 63)) - 1ull));
+        const unsigned long long lanes_before = (1ull << (tid & 63)) - 1ull;
+        const int rank = __popcll(exec_mask & lanes_before);
         const int n_lanes = __popcll(exec_mask);
 
         const vec3 slopes = make_vec3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
@@ -189,9 +203,11 @@
         int depth = 0;
         float node_size = root_size;
 
+        PHASE_END(1)      // entry: root cube, LDS set-up
         for (int step = 0; step < MAX_STEPS && __any(!done); step++) {
             // ---- A: locate the leaf under the current point
             int count = 0, first = 0;
+            PHASE_ADD(5, 1); PHASE_ADD(6, __popcll(__ballot(!done)));
             if (!done) {
                 vec3 ray_pos = origin + seg_begin * ray, node_origin = make_vec3(0.0f, 0.0f, 0.0f);
                 int head = 0, payload = 0, child_idx;
@@ -217,21 +233,22 @@
             pool_origin[tid] = make_float4(origin.x, origin.y, origin.z, seg_end);
             pool_first[tid] = first;
             pool_best[tid] = ~0ull;
+            PHASE_END(2)
 
             // ---- B: inclusive prefix sums of the counts over the lanes of this call
             // (neighbouring rays cross empty space together: a step in which no lane of the wave
             // stands in a leaf with triangles goes straight on to the hop)
             if (__any(count > 0)) {
-            pool_scan[wave_base + rank] = count;
-            POOL_SYNC();
-            for (int d = 1; d < n_lanes; d <<= 1) {
-                const int mine = pool_scan[wave_base + rank];
-                const int left = rank >= d ? pool_scan[wave_base + rank - d] : 0;
-                POOL_SYNC();
-                pool_scan[wave_base + rank] = mine + left;
-                POOL_SYNC();
+            // bit plane b of the counts is one ballot; the lanes before this one that have the bit
+            // set add 2^b to its sum (no LDS traffic, any set of executing lanes)
+            int before = 0, total = 0;
+            for (int b = 0; __any((count >> b) != 0); ++b) {
+                const unsigned long long plane = __ballot((count >> b) & 1);
+                before += __popcll(plane & lanes_before) << b;
+                total += __popcll(plane) << b;
             }
-            const int total = pool_scan[wave_base + n_lanes - 1];
+            pool_scan[wave_base + rank] = before + count;
+            POOL_SYNC();
             // Work item w = (owner lane, triangle j of its leaf).  Two stages, software-pipelined:
             // while the record of item w is on its way from memory, the owner of item w + n_lanes
             // is looked up (a binary search over the prefix sums in LDS) and its record requested.
@@ -284,8 +301,10 @@
                 }
                 cur = next;
             }
+            PHASE_ADD(7, 1); PHASE_ADD(8, total);
             }
             POOL_SYNC();
+            PHASE_END(3)
 
             // ---- C: own result, or hop to the neighbour cell
             if (!done) {
@@ -310,18 +329,30 @@
                     }
                     if (depth == 0) done = true;        // left the root cube
                     else {
+                        // the eight children of a node lie side by side: the neighbour's record is the
+                        // old one moved by the difference of the child numbers (no look at the parent)
+                        const int old_idx = ((cx & 1) ? 4 : 0) + ((cy & 1) ? 2 : 0) + ((cz & 1) ? 1 : 0);
                         cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
                         const int child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
-                        STACK(depth) = octree_data[2*STACK(depth-1)+1] + child_idx;
+                        STACK(depth) = STACK(depth) + (child_idx - old_idx);
                         seg_begin = seg_end;
                         if (seg_begin > t_limit) done = true;
                     }
                 }
             }
             POOL_SYNC();
+            PHASE_END(4)
         }
+        PHASE_ADD(0, 1); PHASE_ADD(9, n_lanes);
+        ### if obj.profile_phases
+        if (rank == 0)
+            for (int slot = 0; slot < 10; ++slot)
+                atomicAdd(&clr_mesh_phases[(blockIdx.x & 63) * 16 + slot], (unsigned long long)phase_sum[slot]);
+        ### endif
         #undef STACK
         #undef POOL_SYNC
+        #undef PHASE_ADD
+        #undef PHASE_END
     ### endcall
 ### endmacro
 
@@ -440,13 +471,12 @@
             }
             if (depth == 0) return;        // left the root cube
 
+            // the eight children of a node lie side by side: the neighbour's record is the old one
+            // moved by the difference of the child numbers (no look at the parent)
+            const int old_idx = ((cx & 1) ? 4 : 0) + ((cy & 1) ? 2 : 0) + ((cz & 1) ? 1 : 0);
             cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
             child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
-            ### if flat
-            STACK(depth) = octree_data[2*STACK(depth-1)+1] + child_idx;
-            ### else
-            STACK(depth) = octree_data[STACK(depth-1)+1] + child_idx*2;
-            ### endif
+            STACK(depth) = STACK(depth) + (child_idx - old_idx){{ '' if flat else '*2' }};
 
             seg_begin = seg_end;
             if (seg_begin > t_limit) return;

@@ -9,6 +9,7 @@ root header last).  Face indices are tracked explicitly, so the reference's late
 ``active_faces`` indexing hazard (octree.py:215-231) is not reproduced; results coincide
 whenever no face drops out of the active set, e.g. the scene-test cube.
 """
+import os
 import numpy
 from .base import Tracer
 
@@ -126,6 +127,8 @@ class Octree(Tracer):
         if layout == 'flat':
             builder = 'native'
         self.pooled = (layout == 'flat') if pooled is None else bool(pooled)
+        # development: cycle counters per phase of the pooled traversal (tools/mesh_phases.py)
+        self.profile_phases = os.environ.get('CLR_MESH_PROFILE') == '1'
         if self.pooled and layout != 'flat':
             raise RuntimeError("pooled triangle tests need the flat layout")
         self.builder, self.layout, self.max_steps = builder, layout, max_steps

@@ -104,6 +104,8 @@ class Renderer:
         self.rng_seed = key * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 & (2**64 - 1)
 
         self._group_objects()
+        # development switch of the mesh traversal (objects/meshes.py): a module global of counters
+        self.profile_mesh_phases = any(getattr(obj.tracer, 'profile_phases', False) for obj in scene.objects)
         self._init_lights()
         self._collect_tracer_data()
         self._init_misc()
