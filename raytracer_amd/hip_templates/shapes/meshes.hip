@@ -147,12 +147,14 @@
     ### call tracer_function_base(obj)
         const int LEVELS = {{ obj.levels }};
         const int MAX_STEPS = {{ obj.max_steps }};
+        #define POOL_WORDS 65                          // 64 words of item bits + one, so that a window may reach past the last item
         __shared__ int stack_lds[{{ obj.levels }} * 256];
         __shared__ float4 pool_origin[256];            // origin.xyz, exit distance of the current leaf
         __shared__ float4 pool_ray[256];               // ray.xyz, face to skip (int bits; -1 = none)
         __shared__ int pool_first[256];                // first triangle record of the lane's leaf
-        __shared__ int pool_scan[256];                 // by rank inside the wave: inclusive prefix sums
-        __shared__ int pool_owner[256];                // by rank: thread index of the owner
+        __shared__ int pool_start[256];                // q-th lane of the wave that stands in a leaf with triangles: its first item
+        __shared__ int pool_owner[256];                //   ... and its thread index
+        __shared__ unsigned long long pool_ends[4 * POOL_WORDS];   // per wave: bit w set = item w is the last one of its owner
         __shared__ unsigned long long pool_best[256];  // per lane: min of (t bits << 32 | index in leaf)
         int *stack = stack_lds + threadIdx.x;
         #define STACK(level) stack[(level) * 256]
@@ -195,7 +197,7 @@
 
         const uint prev_face = *p_subobject;
         pool_ray[tid] = make_float4(ray.x, ray.y, ray.z, __int_as_float(on_surface ? (int)prev_face : -1));
-        pool_owner[wave_base + rank] = tid;
+        unsigned long long *ends = pool_ends + (tid >> 6) * POOL_WORDS;
 
         int cx = 0, cy = 0, cz = 0;       // integer cell coordinates at the current depth
         int bx = 0, by = 0, bz = 0;       // their lowest bits (position inside the parent)
@@ -247,23 +249,66 @@
                 before += __popcll(plane & lanes_before) << b;
                 total += __popcll(plane) << b;
             }
-            pool_scan[wave_base + rank] = before + count;
+            if (total > 64 * (POOL_WORDS - 1)) {
+                // more items than the bitmap of range ends holds (leaves of hundreds of faces at the
+                // depth limit): every lane walks its own leaf; same rule - smallest t, the earlier
+                // triangle on ties
+                const float * __restrict__ rec = tris + 9*first;
+                const int skip_face = on_surface ? (int)prev_face : -1;
+                float best_t = seg_end;
+                int best_j = -1;
+                for (int j = 0; j < count; ++j) {
+                    const clr_f4u r0 = *(const clr_f4u *)(rec + 9*j), r1 = *(const clr_f4u *)(rec + 9*j + 4);
+                    const float r2 = rec[9*j + 8];
+                    if (skip_face >= 0 && skip_face == tri_ids[first + j]) continue;
+                    const vec3 va = make_vec3(r0.x, r0.y, r0.z);
+                    const vec3 e1 = make_vec3(r0.w, r1.x, r1.y);
+                    const vec3 e2 = make_vec3(r1.z, r1.w, r2);
+                    const vec3 pvec = cross(ray, e2);
+                    const float det = dot(e1, pvec);
+                    const float inv_det = 1.f / det;
+                    const vec3 tvec = origin - va;
+                    const float u = dot(tvec, pvec) * inv_det;
+                    if (u < 0.f || u > 1.f) continue;
+                    const vec3 qvec = cross(tvec, e1);
+                    const float v = dot(ray, qvec) * inv_det;
+                    if (v < 0.f || u + v > 1.f) continue;
+                    const float t = dot(e2, qvec) * inv_det;
+                    if (t > 0.0f && t < best_t) { best_t = t; best_j = j; }
+                }
+                if (best_j >= 0) pool_best[tid] = ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned)best_j;
+            } else {
+            // The owner of item w is the q-th lane with triangles, q = number of range ends below w:
+            // a bitmap of the ends in LDS, of which a round looks at the window of its own items.
+            for (int i = rank; i <= ((total - 1) >> 6) + 1; i += n_lanes) ends[i] = 0ull;
+            POOL_SYNC();
+            if (count > 0) {
+                const int q = __popcll(__ballot(1) & lanes_before), last = before + count - 1;
+                pool_owner[wave_base + q] = tid;
+                pool_start[wave_base + q] = before;
+                atomicOr(&ends[last >> 6], 1ull << (last & 63));
+            }
             POOL_SYNC();
             // Work item w = (owner lane, triangle j of its leaf).  Two stages, software-pipelined:
             // while the record of item w is on its way from memory, the owner of item w + n_lanes
-            // is looked up (a binary search over the prefix sums in LDS) and its record requested.
+            // is looked up and its record requested.  Rounds are fetched in order: `ends_below`
+            // counts the range ends before the round being fetched.
             struct PoolItem { int owner, j, face; clr_f4u r0, r1; float r2; };   // owner < 0: none
-            auto pool_fetch = [&](const int w) {
+            int ends_below = 0;
+            const unsigned long long round_lanes = n_lanes == 64 ? ~0ull : (1ull << n_lanes) - 1ull;
+            const unsigned long long ranks_before = (1ull << rank) - 1ull;
+            auto pool_fetch = [&](const int round_base) {
                 PoolItem it;
                 it.owner = -1;
+                if (round_base >= total) return it;
+                const int word = round_base >> 6, shift = round_base & 63;
+                const unsigned long long lo = ends[word], hi = ends[word + 1];
+                const unsigned long long window = (shift ? (lo >> shift) | (hi << (64 - shift)) : lo) & round_lanes;
+                const int w = round_base + rank;
                 if (w < total) {
-                    int lo = 0, hi = n_lanes - 1;                 // first rank whose prefix sum exceeds w
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (pool_scan[wave_base + mid] > w) hi = mid; else lo = mid + 1;
-                    }
-                    it.owner = pool_owner[wave_base + lo];
-                    it.j = w - (lo ? pool_scan[wave_base + lo - 1] : 0);
+                    const int q = ends_below + __popcll(window & ranks_before);
+                    it.owner = pool_owner[wave_base + q];
+                    it.j = w - pool_start[wave_base + q];
                     const int record = pool_first[it.owner] + it.j;
                     const float * __restrict__ rec = tris + 9*record;
                     it.r0 = *(const clr_f4u *)rec; it.r1 = *(const clr_f4u *)(rec + 4);
@@ -271,11 +316,12 @@
                     // the face number matters only to a ray that starts on a face of this mesh
                     it.face = __float_as_int(pool_ray[it.owner].w) < 0 ? -2 : tri_ids[record];
                 }
+                ends_below += __popcll(window);
                 return it;
             };
-            PoolItem cur = pool_fetch(rank);
+            PoolItem cur = pool_fetch(0);
             for (int base = 0; base < total; base += n_lanes) {
-                const PoolItem next = pool_fetch(base + n_lanes + rank);
+                const PoolItem next = pool_fetch(base + n_lanes);
                 float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = o4;
                 if (cur.owner >= 0) { o4 = pool_origin[cur.owner]; d4 = pool_ray[cur.owner]; }
                 if (cur.owner >= 0 && cur.face != __float_as_int(d4.w)) {
@@ -300,6 +346,7 @@
                     }
                 }
                 cur = next;
+            }
             }
             PHASE_ADD(7, 1); PHASE_ADD(8, total);
             }
@@ -351,6 +398,7 @@
         ### endif
         #undef STACK
         #undef POOL_SYNC
+        #undef POOL_WORDS
         #undef PHASE_ADD
         #undef PHASE_END
     ### endcall
