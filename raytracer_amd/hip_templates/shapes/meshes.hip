@@ -93,6 +93,7 @@
 {#- flat layout: 36-byte records (v0, e1, e2) back to back, 4-byte aligned; face ids apart -#}
 ### macro flat_record_types()
         typedef float clr_f4u __attribute__((ext_vector_type(4), aligned(4)));
+        typedef int clr_i2u __attribute__((ext_vector_type(2), aligned(4)));
 ### endmacro
 
 ### macro flat_triangle_loop()
@@ -205,18 +206,24 @@
         int depth = 0;
         float node_size = root_size;
 
+        // `ahead` = record of the node at STACK(depth), asked for one phase early: the root's here,
+        // later the neighbour cell's right after the hop, which is taken before the triangle tests
+        // so that the record travels while they run
+        clr_i2u ahead = *(const clr_i2u *)(octree_data + 2*root_data_offset);
+
         PHASE_END(1)      // entry: root cube, LDS set-up
         for (int step = 0; step < MAX_STEPS && __any(!done); step++) {
             // ---- A: locate the leaf under the current point
             int count = 0, first = 0;
+            bool last_cell = false;       // the ray leaves the tree (or its range) after this cell
             PHASE_ADD(5, 1); PHASE_ADD(6, __popcll(__ballot(!done)));
             if (!done) {
                 vec3 ray_pos = origin + seg_begin * ray, node_origin = make_vec3(0.0f, 0.0f, 0.0f);
                 int head = 0, payload = 0, child_idx;
+                clr_i2u record = ahead;
                 while (depth < LEVELS-1) {
-                    const int at = STACK(depth);
-                    head = octree_data[2*at];          // >= 0: leaf with that many triangles, -1: inner
-                    payload = octree_data[2*at+1];     // first triangle record / first child
+                    head = record.x;                   // >= 0: leaf with that many triangles, -1: inner
+                    payload = record.y;                // first triangle record / first child
                     node_origin = root_origin + make_vec3((float)cx, (float)cy, (float)cz)*node_size;
                     if (head >= 0) break;
                     const vec3 rc = ray_pos - node_origin;
@@ -227,10 +234,38 @@
                     cx = (cx << 1) | bx; cy = (cy << 1) | by; cz = (cz << 1) | bz;
                     node_size *= 0.5f;
                     depth++;
+                    if (depth < LEVELS-1) record = *(const clr_i2u *)(octree_data + 2*(payload + child_idx));
                 }
                 t_out = slopes * (node_origin - origin + far_walls*node_size);
                 seg_end = fminf(fminf(t_out.x, t_out.y), t_out.z);
                 if (head > 0) { count = head; first = payload; }
+
+                // the hop to the neighbour cell does not depend on the triangle tests of this one
+                int hx = 0, hy = 0, hz = 0;
+                if (seg_end == t_out.x) hx = sx;
+                else if (seg_end == t_out.y) hy = sy;
+                else if (seg_end == t_out.z) hz = sz;
+                while (depth > 0) {
+                    bx += hx; by += hy; bz += hz;
+                    if (bx >= 0 && bx <= 1 && by >= 0 && by <= 1 && bz >= 0 && bz <= 1) break;
+                    depth--;
+                    cx >>= 1; cy >>= 1; cz >>= 1;
+                    bx = cx & 1; by = cy & 1; bz = cz & 1;
+                    node_size *= 2.0f;
+                }
+                if (depth == 0) last_cell = true;        // leaves the root cube
+                else {
+                    // the eight children of a node lie side by side: the neighbour's record is the
+                    // old one moved by the difference of the child numbers (no look at the parent)
+                    const int old_idx = ((cx & 1) ? 4 : 0) + ((cy & 1) ? 2 : 0) + ((cz & 1) ? 1 : 0);
+                    cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
+                    child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
+                    const int at = STACK(depth) + (child_idx - old_idx);
+                    STACK(depth) = at;
+                    seg_begin = seg_end;
+                    if (seg_begin > t_limit) last_cell = true;
+                    else ahead = *(const clr_i2u *)(octree_data + 2*at);
+                }
             }
             pool_origin[tid] = make_float4(origin.x, origin.y, origin.z, seg_end);
             pool_first[tid] = first;
@@ -353,7 +388,7 @@
             POOL_SYNC();
             PHASE_END(3)
 
-            // ---- C: own result, or hop to the neighbour cell
+            // ---- C: own result, or on to the cell the hop went to
             if (!done) {
                 const unsigned long long best = pool_best[tid];
                 if (best != ~0ull) {
@@ -361,31 +396,7 @@
                     *p_subobject = (uint)tri_ids[first + (int)(best & 0xffffffffull)];
                     done = true;
                 }
-                else {
-                    int hx = 0, hy = 0, hz = 0;
-                    if (seg_end == t_out.x) hx = sx;
-                    else if (seg_end == t_out.y) hy = sy;
-                    else if (seg_end == t_out.z) hz = sz;
-                    while (depth > 0) {
-                        bx += hx; by += hy; bz += hz;
-                        if (bx >= 0 && bx <= 1 && by >= 0 && by <= 1 && bz >= 0 && bz <= 1) break;
-                        depth--;
-                        cx >>= 1; cy >>= 1; cz >>= 1;
-                        bx = cx & 1; by = cy & 1; bz = cz & 1;
-                        node_size *= 2.0f;
-                    }
-                    if (depth == 0) done = true;        // left the root cube
-                    else {
-                        // the eight children of a node lie side by side: the neighbour's record is the
-                        // old one moved by the difference of the child numbers (no look at the parent)
-                        const int old_idx = ((cx & 1) ? 4 : 0) + ((cy & 1) ? 2 : 0) + ((cz & 1) ? 1 : 0);
-                        cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
-                        const int child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
-                        STACK(depth) = STACK(depth) + (child_idx - old_idx);
-                        seg_begin = seg_end;
-                        if (seg_begin > t_limit) done = true;
-                    }
-                }
+                else if (last_cell) done = true;
             }
             POOL_SYNC();
             PHASE_END(4)
