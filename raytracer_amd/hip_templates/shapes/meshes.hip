@@ -140,7 +140,7 @@
          every lane - also one that has finished its own traversal - takes list entry
          round*A + rank, finds the owner by binary search in the prefix sums, reads the owner's
          ray from LDS and tests the triangle with the arithmetic of flat_triangle_loop; a hit
-         goes to the owner with a 64-bit LDS minimum on (t bits, index in the leaf), which is
+         goes to the owner with a 64-bit LDS minimum on (t bits, record number), which is
          the sequential rule "smallest t, earlier triangle on ties";
       C  each lane reads its own minimum and either returns the hit or hops to the next cell.
     A lane never leaves the loop before all lanes of the call are done. -#}
@@ -152,9 +152,8 @@
         __shared__ int stack_lds[{{ obj.levels }} * 256];
         __shared__ float4 pool_origin[256];            // origin.xyz, exit distance of the current leaf
         __shared__ float4 pool_ray[256];               // ray.xyz, face to skip (int bits; -1 = none)
-        __shared__ int pool_first[256];                // first triangle record of the lane's leaf
-        __shared__ int pool_start[256];                // q-th lane of the wave that stands in a leaf with triangles: its first item
-        __shared__ int pool_owner[256];                //   ... and its thread index
+        __shared__ int2 pool_owner[256];               // q-th lane of the wave that stands in a leaf with triangles:
+                                                       // (thread index, first record of the leaf - first item of the lane)
         __shared__ unsigned long long pool_ends[4 * POOL_WORDS];   // per wave: bit w set = item w is the last one of its owner
         __shared__ unsigned long long pool_best[256];  // per lane: min of (t bits << 32 | index in leaf)
         int *stack = stack_lds + threadIdx.x;
@@ -268,7 +267,6 @@
                 }
             }
             pool_origin[tid] = make_float4(origin.x, origin.y, origin.z, seg_end);
-            pool_first[tid] = first;
             pool_best[tid] = ~0ull;
             PHASE_END(2)
 
@@ -311,7 +309,7 @@
                     const float t = dot(e2, qvec) * inv_det;
                     if (t > 0.0f && t < best_t) { best_t = t; best_j = j; }
                 }
-                if (best_j >= 0) pool_best[tid] = ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned)best_j;
+                if (best_j >= 0) pool_best[tid] = ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned)(first + best_j);
             } else {
             // The owner of item w is the q-th lane with triangles, q = number of range ends below w:
             // a bitmap of the ends in LDS, of which a round looks at the window of its own items.
@@ -319,8 +317,7 @@
             POOL_SYNC();
             if (count > 0) {
                 const int q = __popcll(__ballot(1) & lanes_before), last = before + count - 1;
-                pool_owner[wave_base + q] = tid;
-                pool_start[wave_base + q] = before;
+                pool_owner[wave_base + q] = make_int2(tid, first - before);
                 atomicOr(&ends[last >> 6], 1ull << (last & 63));
             }
             POOL_SYNC();
@@ -328,7 +325,7 @@
             // while the record of item w is on its way from memory, the owner of item w + n_lanes
             // is looked up and its record requested.  Rounds are fetched in order: `ends_below`
             // counts the range ends before the round being fetched.
-            struct PoolItem { int owner, j, face; clr_f4u r0, r1; float r2; };   // owner < 0: none
+            struct PoolItem { int owner, record, face; clr_f4u r0, r1; float r2; };   // owner < 0: none
             int ends_below = 0;
             const unsigned long long round_lanes = n_lanes == 64 ? ~0ull : (1ull << n_lanes) - 1ull;
             const unsigned long long ranks_before = (1ull << rank) - 1ull;
@@ -342,9 +339,9 @@
                 const int w = round_base + rank;
                 if (w < total) {
                     const int q = ends_below + __popcll(window & ranks_before);
-                    it.owner = pool_owner[wave_base + q];
-                    it.j = w - pool_start[wave_base + q];
-                    const int record = pool_first[it.owner] + it.j;
+                    const int2 owner = pool_owner[wave_base + q];
+                    it.owner = owner.x;
+                    const int record = it.record = w + owner.y;
                     const float * __restrict__ rec = tris + 9*record;
                     it.r0 = *(const clr_f4u *)rec; it.r1 = *(const clr_f4u *)(rec + 4);
                     it.r2 = rec[8];
@@ -376,7 +373,7 @@
                             const float t = dot(e2, qvec) * inv_det;
                             if (t > 0.0f && t < o4.w)
                                 atomicMin(&pool_best[cur.owner],
-                                          ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)cur.j);
+                                          ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)cur.record);
                         }
                     }
                 }
@@ -393,7 +390,7 @@
                 const unsigned long long best = pool_best[tid];
                 if (best != ~0ull) {
                     *t_hit = __uint_as_float((uint)(best >> 32));
-                    *p_subobject = (uint)tri_ids[first + (int)(best & 0xffffffffull)];
+                    *p_subobject = (uint)tri_ids[(int)(best & 0xffffffffull)];
                     done = true;
                 }
                 else if (last_cell) done = true;
