@@ -6,6 +6,10 @@
 ### if renderer.profile_mesh_phases
 __device__ unsigned long long clr_mesh_phases[64 * 16];
 ### endif
+### if renderer.profile_blocks
+// development (tools/block_costs.py): cycles of the slowest wave of every block of clr_render
+__device__ unsigned long long clr_block_cycles[65536];
+### endif
 
 // ---- scene tables, filled by the host after the module is loaded
 // clr_params, per object: declared parameters, then 4 rows of the inverse affine
@@ -391,6 +395,9 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
            float * __restrict__ pass_log, const int pass_groups, const int pass_stride)
 {
     float4 * __restrict__ const dbg = {{ 'dbg_argument' if debug else 'nullptr' }};
+### if renderer.profile_blocks
+    const long long clr_block_begin = (long long)__builtin_readcyclecounter();
+### endif
 ### if renderer.split_passes
     // pass-split mode: lane (k, group) walks the passes [group * per_group, ...) of pixel k and
     // logs what it would have added to the pixel (layout: clr_acc, shader.hip)
@@ -567,6 +574,10 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
 ### endif
 ### if not renderer.split_passes
     if (in_image) img[k] = make_float4(acc.v.x, acc.v.y, acc.v.z, img0.w);
+### endif
+### if renderer.profile_blocks
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536)
+        atomicMax(&clr_block_cycles[blockIdx.x], (unsigned long long)((long long)__builtin_readcyclecounter() - clr_block_begin));
 ### endif
 }
 {%- endmacro %}

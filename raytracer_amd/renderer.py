@@ -105,6 +105,7 @@ class Renderer:
 
         self._group_objects()
         # development switch of the mesh traversal (objects/meshes.py): a module global of counters
+        self.profile_blocks = os.environ.get('CLR_BLOCK_PROFILE') == '1'     # development, tools/block_costs.py
         self.profile_mesh_phases = any(getattr(obj.tracer, 'profile_phases', False) for obj in scene.objects)
         self._init_lights()
         self._collect_tracer_data()
