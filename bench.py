@@ -72,6 +72,9 @@ def parse_args():
                     help='1/0: pass-split program (several lanes per pixel) on/off; default: on for small frames')
     ap.add_argument('--pass-groups', type=int, default=None,
                     help='pass-split program: lanes per pixel at least (default: 4 for mesh scenes, else 1)')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='launch chains: every step goes out as this many launches on slices of the frame, each '
+                         'slice on its own stream, so that one slice fills the GPU while another drains (1: one stream)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
@@ -188,7 +191,7 @@ def main():
                  build_options=args.build_options.split() if args.build_options else None,
                  bake_parameters=None if args.bake is None else bool(args.bake),
                  split_passes=None if args.split_passes is None else bool(args.split_passes),
-                 **shard.renderer_arguments())
+                 overlap_parts=args.streams, **shard.renderer_arguments())
     if args.pass_groups:
         r.min_pass_groups = args.pass_groups
     shard.configure(r)                          # per-pixel random numbers are keyed by the GLOBAL pass index
@@ -232,6 +235,7 @@ def main():
     r.acc.timer_begin()
     for k in range(args.steps):
         r.render_resident(k * P, P, timed=False)
+    r.join_parts()                     # the default stream waits for the slices' streams (it would anyway)
     kernel_ms_total = r.acc.timer_end(wait=False)
     shard.combine(frame, dist)         # passes: all-reduce of the private sums; tiles: all-gather
     if rank == 0:
@@ -260,6 +264,7 @@ def main():
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'speculative_exact_arithmetic': bool(r.speculate),
                    'occupancy_hint': r.min_waves_per_simd,
+                   'launches_per_step': (len(r.part_bounds()) - 1) if not r.split_passes else 1,
                    'kernel_registers': {key.lstrip('.'): value for key, value in getattr(r, 'kernel_metadata', {}).items()
                                         if key in ('.vgpr_count', '.sgpr_count', '.vgpr_spill_count',
                                                    '.sgpr_spill_count', '.private_segment_fixed_size',

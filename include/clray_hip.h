@@ -44,6 +44,16 @@ int clr_ctx_create(int device_index, clr_ctx **out);
 int clr_ctx_destroy(clr_ctx *ctx);
 int clr_device_info(clr_ctx *ctx, clr_device_info_t *out);
 int clr_sync(clr_ctx *ctx, void *stream);
+/* Further in-order queues of the context's GPU (the reference has the one queue of
+ * accelerator.py:28-29).  Launch chains that touch disjoint slices of the frame can go to streams of
+ * their own: the blocks of one chain then fill the GPU while the last blocks of another drain
+ * (DESIGN section 6).  The streams are ordinary (blocking) HIP streams: work on the default stream
+ * (NULL) - copies, fills, clr_timer_* - waits for them and they wait for it.  clr_stream_wait
+ * makes `waiting` (NULL = default stream) wait for everything queued on `on` so far, without
+ * blocking the host. */
+int clr_stream_create(clr_ctx *ctx, void **stream);
+int clr_stream_destroy(clr_ctx *ctx, void *stream);
+int clr_stream_wait(clr_ctx *ctx, void *waiting, void *on);
 
 /* ---- program: replaces Accelerator.build_program (accelerator.py:43-49).  `source` is the
  * scene-specialised HIP translation unit; it is compiled with hiprtc for gfx950 (or for

@@ -76,6 +76,9 @@ def load_library():
         'clr_ctx_destroy': (ci, [vp]),
         'clr_device_info': (ci, [vp, P(DeviceInfo)]),
         'clr_sync': (ci, [vp, vp]),
+        'clr_stream_create': (ci, [vp, P(vp)]),
+        'clr_stream_destroy': (ci, [vp, vp]),
+        'clr_stream_wait': (ci, [vp, vp, vp]),
         'clr_timer_begin': (ci, [vp, vp]),
         'clr_timer_end': (ci, [vp, vp]),
         'clr_timer_elapsed': (ci, [vp, P(ctypes.c_float)]),
@@ -326,6 +329,7 @@ class Accelerator:
         _check(self.lib.clr_ctx_create(int(device_index), ctypes.byref(ctx)))
         self.ctx = ctx
         self.prog = None
+        self._streams = []
         self.profiling_info = {}
         self.last_code = None
 
@@ -334,6 +338,9 @@ class Accelerator:
             self.lib.clr_program_destroy(self.prog)
             self.prog = None
         if self.ctx:
+            for stream in getattr(self, '_streams', []):
+                self.lib.clr_stream_destroy(self.ctx, stream)
+            self._streams = []
             self.lib.clr_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -345,6 +352,18 @@ class Accelerator:
 
     def finish(self, stream=None):
         _check(self.lib.clr_sync(self.ctx, stream))
+
+    def new_stream(self):
+        """A further in-order queue of this GPU (ordinary HIP stream; the default stream and it wait
+        for each other's earlier work).  Released with the accelerator."""
+        stream = ctypes.c_void_p()
+        _check(self.lib.clr_stream_create(self.ctx, ctypes.byref(stream)))
+        self._streams.append(stream)
+        return stream
+
+    def stream_wait(self, waiting, on):
+        """`waiting` (None = default stream) waits for what is queued on `on` so far; the host does not."""
+        _check(self.lib.clr_stream_wait(self.ctx, waiting, on))
 
     def timer_begin(self, stream=None):
         """Start of a timed region of launches on `stream` (one HIP event pair around all of them)."""

@@ -263,6 +263,34 @@ int clr_sync(clr_ctx *ctx, void *stream) {
     return 0;
 }
 
+int clr_stream_create(clr_ctx *ctx, void **stream) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!stream) return fail("null output pointer");
+    hipStream_t s = nullptr;
+    CLR_TRY(hipStreamCreate(&s));
+    *stream = (void *)s;
+    return 0;
+}
+
+int clr_stream_destroy(clr_ctx *ctx, void *stream) {
+    if (int rc = set_device(ctx)) return rc;
+    if (!stream) return 0;
+    CLR_TRY(hipStreamSynchronize((hipStream_t)stream));
+    CLR_TRY(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
+int clr_stream_wait(clr_ctx *ctx, void *waiting, void *on) {
+    if (int rc = set_device(ctx)) return rc;
+    if (waiting == on) return 0;
+    hipEvent_t reached;
+    CLR_TRY(hipEventCreateWithFlags(&reached, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(reached, (hipStream_t)on);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiting, reached, 0);
+    (void)hipEventDestroy(reached);      // released once the recorded work has completed
+    return check(e, "clr_stream_wait");
+}
+
 int clr_timer_begin(clr_ctx *ctx, void *stream) {
     if (int rc = set_device(ctx)) return rc;
     CLR_TRY(hipEventRecord(ctx->timer_start, (hipStream_t)stream));

@@ -74,8 +74,16 @@ class Renderer:
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
                  min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None,
-                 regenerate=None, light_samples=1):
+                 regenerate=None, light_samples=1, overlap_parts=1):
         self.scene = scene
+        # Launch chains on slices of the frame: with k > 1 every launch of
+        # render_resident goes out as k launches, one per contiguous slice of the ray order, each
+        # slice on a stream of its own.  A slice's launches stay in order, those of different
+        # slices overlap, so the blocks of one fill the GPU while the last blocks of another
+        # drain.  No pixel changes (a pixel belongs to one slice).  One-lane-per-pixel programs
+        # only; 1 = everything on the caller's stream, as the reference's single queue.
+        self.overlap_parts = max(1, int(overlap_parts))
+        self._part_streams = []
         # next-event estimation with k points of the segment's light instead of one (no
         # counterpart in the reference, k = 1 is its estimator).  The light is still picked once per
         # segment; its contribution is the mean over the k points, each with its own visibility test.
@@ -542,16 +550,48 @@ class Renderer:
                       for f in range(first, first + count, most)]
                 return sum(ms) if timed else None
         rows = self.dev_rows[first:first + count].ptr if self.dev_rows is not None else None
-        args = RenderArgs(
-            img=self.img.ptr, cam=self.cam.ptr,
-            pass_tape=self.dev_pass_tape[first:first + count].ptr,
-            bounce_tape=self.dev_bounce_tape[first:first + count].ptr if self.dev_bounce_tape is not None else None,
-            material_rows=rows,
-            vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
-            n_pixels=self.n_pixels, n_passes=count, regenerate=int(self.regenerate),
-            debug_dump=None, **self._split_args(count, static_log=static_log),
-            **self._rng_args(self._resident_first_pass + first * self.pass_stride))
-        return self.acc.render_passes(args, stream=stream, timed=timed, static_log=static_log)
+
+        def launch(lo, hi, on_stream, timed_launch):
+            rng = self._rng_args(self._resident_first_pass + first * self.pass_stride)
+            rng['first_ray'] += lo
+            args = RenderArgs(
+                img=self.img.ptr + 16 * lo, cam=self.cam.ptr + 16 * lo,
+                pass_tape=self.dev_pass_tape[first:first + count].ptr,
+                bounce_tape=self.dev_bounce_tape[first:first + count].ptr if self.dev_bounce_tape is not None else None,
+                material_rows=rows,
+                vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
+                n_pixels=hi - lo, n_passes=count, regenerate=int(self.regenerate),
+                debug_dump=None, **self._split_args(count, static_log=static_log), **rng)
+            return self.acc.render_passes(args, stream=on_stream, timed=timed_launch, static_log=static_log)
+
+        parts = self.part_bounds() if stream is None and not self.split_passes else [0, self.n_pixels]
+        if len(parts) == 2:
+            return launch(0, self.n_pixels, stream, timed)
+        while len(self._part_streams) < len(parts) - 1:
+            self._part_streams.append(self.acc.new_stream())
+        if timed:
+            self.acc.timer_begin()
+        for p in range(len(parts) - 1):
+            launch(parts[p], parts[p + 1], self._part_streams[p], False)
+        if timed:
+            self.join_parts()
+            ms = self.acc.timer_end()
+            self.acc._record('clr_render', ms * 1e-3, ms * 1e-3)
+            return ms
+        return None
+
+    def part_bounds(self):
+        """Ray indices at which the frame is cut into overlap_parts slices (multiples of the block size)."""
+        k = min(self.overlap_parts, max(1, self.n_pixels // 4096))
+        cuts = [((self.n_pixels * p // k + 255) // 256) * 256 for p in range(k)] + [self.n_pixels]
+        cuts[0] = 0
+        return cuts
+
+    def join_parts(self, stream=None):
+        """`stream` (None: the default stream) waits for the launches on the slices' streams.  Work
+        on the default stream does so by itself (ordinary HIP streams); this is for other streams."""
+        for part_stream in self._part_streams:
+            self.acc.stream_wait(stream, part_stream)
 
     def max_passes_per_launch(self):
         """Passes one launch of a pass-split program may cover so that its addend log stays below

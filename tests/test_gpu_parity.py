@@ -776,3 +776,36 @@ def test_find_non_negative_and_device_memcpy():
     assert np.array_equal(copy.get()[:10], values[:10]) and (copy.get()[10:] == 0).all()
     acc.device_memcpy(copy, src)
     assert np.array_equal(copy.get(), values)
+
+
+@pytest.mark.parametrize('rng_mode', ['tape', 'philox'])
+def test_launch_chains_on_slices_of_the_frame_change_no_pixel(rng_mode):
+    """Renderer(overlap_parts=k): every launch goes out as k launches on contiguous slices of the
+    ray order, each slice on a stream of its own (clr_stream_create), un-timed launches not waited
+    for.  Same image bit for bit as one launch per step, also for a tile of the frame (ray_range)
+    and when reads on the default stream follow directly."""
+    scene = load_scene('scene-dev', (320, 240))
+    one = Renderer(scene, seed=9, rng_mode=rng_mode, split_passes=False)
+    tape = one.make_tape(0, 12)
+    one.upload_tape(tape)
+    for first in (0, 4, 8):
+        one.render_resident(first, 4)
+    want = one.img.get()
+    for parts, ray_range in ((3, None), (2, (256 * 40, 256 * 100))):      # ray_range = (first ray, count)
+        r = Renderer(load_scene('scene-dev', (320, 240)), seed=9, rng_mode=rng_mode, split_passes=False,
+                     overlap_parts=parts, ray_range=ray_range)
+        assert len(r.part_bounds()) == parts + 1
+        r.upload_tape(tape)
+        for first in (0, 4, 8):
+            assert r.render_resident(first, 4, timed=False) is None
+        got = r.img.get()                                      # a copy on the default stream: waits for the slices
+        lo, hi = (ray_range[0], ray_range[0] + ray_range[1]) if ray_range else (0, one.n_pixels)
+        assert np.array_equal(bits(got), bits(want[lo:hi])), (parts, ray_range)
+        assert len(r._part_streams) == parts
+        # timed launches report the time of the whole step
+        r.img.fill(0)
+        ms = r.render_resident(0, 4)
+        assert ms > 0
+    # a frame too small to cut stays on one stream
+    small = Renderer(load_scene('scene-dev', (64, 48)), seed=9, overlap_parts=4)
+    assert small.part_bounds() == [0, 64 * 48]
