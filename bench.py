@@ -264,7 +264,7 @@ def main():
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'speculative_exact_arithmetic': bool(r.speculate),
                    'occupancy_hint': r.min_waves_per_simd,
-                   'launches_per_step': (len(r.part_bounds()) - 1) if not r.split_passes else 1,
+                   'launches_per_step': len(r.part_bounds()) - 1,
                    'kernel_registers': {key.lstrip('.'): value for key, value in getattr(r, 'kernel_metadata', {}).items()
                                         if key in ('.vgpr_count', '.sgpr_count', '.vgpr_spill_count',
                                                    '.sgpr_spill_count', '.private_segment_fixed_size',

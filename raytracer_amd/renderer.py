@@ -80,8 +80,8 @@ class Renderer:
         # render_resident goes out as k launches, one per contiguous slice of the ray order, each
         # slice on a stream of its own.  A slice's launches stay in order, those of different
         # slices overlap, so the blocks of one fill the GPU while the last blocks of another
-        # drain.  No pixel changes (a pixel belongs to one slice).  One-lane-per-pixel programs
-        # only; 1 = everything on the caller's stream, as the reference's single queue.
+        # drain.  No pixel changes (a pixel belongs to one slice).  1 = everything on the caller's
+        # stream, as the reference's single queue.
         self.overlap_parts = max(1, int(overlap_parts))
         self._part_streams = []
         # next-event estimation with k points of the segment's light instead of one (no
@@ -561,10 +561,15 @@ class Renderer:
                 material_rows=rows,
                 vector_data=self.dev_vector_data.ptr, integer_data=self.dev_integer_data.ptr,
                 n_pixels=hi - lo, n_passes=count, regenerate=int(self.regenerate),
-                debug_dump=None, **self._split_args(count, static_log=static_log), **rng)
+                debug_dump=None, **split, **rng)
+            if split and lo and not static_log:
+                # a slice's part of the addend log: the log is (pass, float, pixel) with the slice's
+                # own pixel count as the stride, so the slices' logs lie one after the other
+                args.pass_log += 4 * count * (1 + 6 * self.scene.max_bounces) * lo
             return self.acc.render_passes(args, stream=on_stream, timed=timed_launch, static_log=static_log)
 
-        parts = self.part_bounds() if stream is None and not self.split_passes else [0, self.n_pixels]
+        split = self._split_args(count, static_log=static_log)
+        parts = self.part_bounds() if stream is None and not static_log else [0, self.n_pixels]
         if len(parts) == 2:
             return launch(0, self.n_pixels, stream, timed)
         while len(self._part_streams) < len(parts) - 1:

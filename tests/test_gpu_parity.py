@@ -806,6 +806,12 @@ def test_launch_chains_on_slices_of_the_frame_change_no_pixel(rng_mode):
         r.img.fill(0)
         ms = r.render_resident(0, 4)
         assert ms > 0
+    # a pass-split program: every slice has its own part of the addend log
+    r = Renderer(load_scene('scene-dev', (320, 240)), seed=9, rng_mode=rng_mode, split_passes=True, overlap_parts=3)
+    r.upload_tape(tape)
+    for first in (0, 4, 8):
+        r.render_resident(first, 4, timed=False)
+    assert np.array_equal(bits(r.img.get()), bits(want))
     # a frame too small to cut stays on one stream
     small = Renderer(load_scene('scene-dev', (64, 48)), seed=9, overlap_parts=4)
     assert small.part_bounds() == [0, 64 * 48]
