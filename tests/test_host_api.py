@@ -571,3 +571,18 @@ def test_light_samples_extend_the_tape_record():
     assert len({tuple(rec[5]) for rec in t4.reshape(-1, 11, 4)}) == t4.shape[0] * t4.shape[1]
     with pytest.raises(ValueError):
         Renderer(load_scene('scene-dev', (32, 24)), device=False, light_samples=0)
+
+
+def test_slices_of_the_frame_for_launch_chains():
+    """Renderer.part_bounds: the frame cut into overlap_parts slices of contiguous rays at multiples
+    of the block size; frames too small to be worth it stay whole."""
+    for size, parts, want_parts in (((1920, 1080), 2, 2), ((1920, 1080), 3, 3), ((320, 240), 8, 8),
+                                    ((320, 240), 64, 18), ((64, 48), 4, 1), ((100, 77), 2, 1)):
+        r = Renderer(load_scene('scene-dev', size), device=False, overlap_parts=parts)
+        cuts = r.part_bounds()
+        assert cuts[0] == 0 and cuts[-1] == r.n_pixels and len(cuts) == want_parts + 1, (size, parts, cuts)
+        assert all(b > a for a, b in zip(cuts, cuts[1:]))
+        assert all(c % 256 == 0 for c in cuts[:-1])
+        sizes = np.diff(cuts)
+        assert sizes.max() - sizes.min() <= 512
+    assert Renderer(load_scene('scene-dev', (320, 240)), device=False).part_bounds() == [0, 320 * 240]

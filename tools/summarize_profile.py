@@ -25,6 +25,19 @@ def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 
+def busy_span(intervals):
+    """Total time covered by at least one of the (start, end) intervals."""
+    total, cur_start, cur_end = 0, None, None
+    for b, e in intervals:
+        if cur_end is None or b > cur_end:
+            if cur_end is not None:
+                total += cur_end - cur_start
+            cur_start, cur_end = b, e
+        else:
+            cur_end = max(cur_end, e)
+    return total + (cur_end - cur_start if cur_end is not None else 0)
+
+
 def main(tag, key, src=None):
     global SRC
     if src:
@@ -57,6 +70,23 @@ def main(tag, key, src=None):
         'hbm_read_bytes_per_launch': fetch, 'hbm_write_bytes_per_launch': write,
         'hbm_bytes_per_launch': fetch + write,
     }
+    # the default run's launch chains (bench.py --streams 2): launches of slices of the frame that
+    # overlap; span = first start to last end of all clr_render launches of that run
+    chains = glob.glob(os.path.join(SRC, 'trace_chains', '*', '*_kernel_trace.csv'))
+    if chains:
+        shutil.copy(newest(os.path.join(SRC, 'trace_chains', '*', '*_kernel_stats.csv')),
+                    os.path.join(DST, tag + '_chains_kernel_stats.csv'))
+        crow = [r for r in csv.DictReader(open(max(chains, key=os.path.getmtime))) if r['Kernel_Name'] == 'clr_render']
+        starts = [int(r['Start_Timestamp']) for r in crow]
+        ends = [int(r['End_Timestamp']) for r in crow]
+        per_step = max(1, round(summary['grid'] / max(int(r['Grid_Size_X']) for r in crow)))
+        steps = len(crow) / per_step
+        # the longest gap-free stretch is the timed loop; warm-up launches are waited for one by one
+        summary['launch_chains'] = {
+            'launches': len(crow), 'launches_per_step': per_step,
+            'avg_launch_ms': sum(e - b for b, e in zip(starts, ends)) / len(crow) / 1e6,
+            'busy_ms_per_step': busy_span(sorted(zip(starts, ends))) / steps / 1e6,
+        }
     c = counters
     if 'SQ_INSTS_VALU' in c and 'SQ_WAVES' in c:
         summary['valu_insts_per_wave'] = c['SQ_INSTS_VALU'] / c['SQ_WAVES']
