@@ -22,8 +22,13 @@ class Sphere(Tracer):
 
     # ---- light interface (only Sphere implements it, as in the reference)
     def _check_no_distortion(self):
+        # asked per light point, i.e. per path segment of every pass: checked once per pose
+        # (every transformation installs a new Affine)
+        if getattr(self, '_undistorted_pose', None) is self.coordinates:
+            return
         if not self.coordinates.is_orthogonal():
             raise RuntimeError("illegal operation for scaled sphere")
+        self._undistorted_pose = self.coordinates
 
     def surface_area(self):
         self._check_no_distortion()

@@ -46,5 +46,21 @@ for parts in (1, 2, 3, 4, 8):
     image = r.img.get()
     if reference is None:
         reference = image
+    if parts == 2:
+        # the same with the second chain half a launch behind the first from the start
+        for rep in range(3):
+            r.img.fill(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            launch(0, P // 2, bounds[1], bounds[2], streams[1].cuda_stream)
+            for k in range(steps):
+                launch(k * P, P, bounds[0], bounds[1], streams[0].cuda_stream)
+                if k + 1 < steps:
+                    launch(k * P + P // 2, P, bounds[1], bounds[2], streams[1].cuda_stream)
+            launch(steps * P - P // 2, P // 2, bounds[1], bounds[2], streams[1].cuda_stream)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t0) * 1e3 / steps
+        same2 = np.array_equal(r.img.get().view(np.uint32), reference.view(np.uint32))
+        print('2 parts, staggered: %.4f ms per %d passes = %.1f Msamples/s, image identical: %s' % (ms2, P, n * P / ms2 / 1e3, same2))
     same = np.array_equal(image.view(np.uint32), reference.view(np.uint32))
     print('%d part(s): %.4f ms per %d passes = %.1f Msamples/s, image identical: %s' % (parts, ms, P, n * P / ms / 1e3, same))
