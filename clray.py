@@ -83,8 +83,11 @@ def main():
     renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device, rng_mode=args.rng,
                                       light_samples=args.light_samples, overlap_parts=2, **shard.renderer_arguments())
     shard.configure(renderer)
-    if scene.samples_per_pixel >= 64:
-        renderer.tune_occupancy(passes=8)       # pays off for long renders only
+    # Timing the occupancy candidates costs six more program builds (about a minute).  Kernels of
+    # analytic primitives run the same at every candidate; ray marchers and meshes differ by up
+    # to 20 %, which pays off from a few minutes of rendering on.
+    if not renderer.speculate and renderer.n_pixels * scene.samples_per_pixel >= 2e11:
+        renderer.tune_occupancy(passes=8)
     acc = renderer.acc
     if use_dist:
         # the accumulator lives in a torch tensor so that RCCL can combine the ranks' results
