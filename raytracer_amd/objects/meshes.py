@@ -102,6 +102,9 @@ class TriangleMesh(Tracer):
 EMPTY_HEADER = [0x100, -99999]
 
 
+POOLED_FROM_FACES = 30000     # meshes from this size on get the pooled triangle tests by default
+
+
 class Octree(Tracer):
 
     MAX_DEPTH = 7
@@ -113,7 +116,7 @@ class Octree(Tracer):
         layout: 'stream' = the reference's integer stream; 'flat' = flattened nodes + per-leaf
         pre-gathered triangle records (needs the native builder).
         max_steps: leaf-step budget of the traversal (300 in the reference).
-        pooled (flat layout only, default on): the triangle tests of all lanes of a wave are
+        pooled (flat layout only; default: from POOLED_FROM_FACES faces on): the triangle tests of all lanes of a wave are
         pooled and dealt out evenly, so lanes whose ray left the mesh or sits in a small leaf
         work on the leaves of the others (same tests, same results).
         overlap (native builder): 'reference' = the reference's bounding-sphere rule for filing a
@@ -126,7 +129,11 @@ class Octree(Tracer):
         self.overlap = overlap
         if layout == 'flat':
             builder = 'native'
-        self.pooled = (layout == 'flat') if pooled is None else bool(pooled)
+        # measured on the torus knot (tools/mesh_sweep.sh, Msamples/s pooled / per lane): 1.4 k faces
+        # 4442 / 5863, 10 k 3065 / 3403, 90 k 2510 / 1994, 1 M 1661 / 1085
+        if pooled is None:
+            pooled = layout == 'flat' and len(triangle_mesh.faces) >= POOLED_FROM_FACES
+        self.pooled = bool(pooled)
         # development: cycle counters per phase of the pooled traversal (tools/mesh_phases.py)
         self.profile_phases = os.environ.get('CLR_MESH_PROFILE') == '1'
         if self.pooled and layout != 'flat':

@@ -44,7 +44,7 @@ def load_scene(name, size=None, **overrides):
         if layout == 'flat-lanes':
             scene = make(n_u, n_v, layout='flat', pooled=False, overlap=overlap)
         else:
-            scene = make(n_u, n_v, layout=layout, overlap=overlap)
+            scene = make(n_u, n_v, layout=layout, overlap=overlap, pooled=True if layout == 'flat' else None)
     else:
         scene = runpy.run_path(os.path.join(SCENE_DIR, name + '.py'))['scene']
     if size is not None:
