@@ -109,13 +109,33 @@ def main():
 
     total = scene.samples_per_pixel
     batch = args.batch or max(1, min(args.itr_per_refresh, 64))
-    done = 0
-    next_refresh = min(max(1, args.itr_per_refresh // 10), total)
-    while done < total:
-        n = min(batch, total - done, max(next_refresh - done, 1))
+
+    def schedule():
+        """(first pass, passes, refresh afterwards) of every batch; refreshes come after a tenth of
+        -itr passes at first and every -itr passes from then on, as in the reference's loop."""
+        at, next_refresh = 0, min(max(1, args.itr_per_refresh // 10), total)
+        while at < total:
+            n = min(batch, total - at, max(next_refresh - at, 1))
+            at += n
+            refresh = at >= next_refresh or at == total
+            if refresh:
+                step = args.itr_per_refresh if at >= args.itr_per_refresh else max(1, args.itr_per_refresh // 10)
+                next_refresh = min(at + step, total)
+            yield at - n, n, refresh
+
+    # The random numbers of a batch are drawn on the host (the reference's generator, in its order):
+    # a helper thread draws batch i + 1 while the GPU renders batch i (the launch waits inside the
+    # library, outside the interpreter lock).
+    from concurrent.futures import ThreadPoolExecutor
+    plan = list(schedule())
+    helper = ThreadPoolExecutor(1)
+    drawn = helper.submit(renderer.make_tape, plan[0][0], plan[0][1]) if plan else None
+    for i, (done, n, refresh) in enumerate(plan):
         # passes [done, done + n) of the global sequence; with the passes partition this rank
         # renders those whose index is rank modulo the number of GPUs
-        tape = renderer.make_tape(done, n)
+        tape = drawn.result()
+        if i + 1 < len(plan):
+            drawn = helper.submit(renderer.make_tape, plan[i + 1][0], plan[i + 1][1])
         mine = shard.local_tape(tape) if shard.pass_stride == 1 else tuple(
             x[(shard.pass_offset - done) % world::world] if x is not None else None for x in tape)
         if mine[0].shape[0]:
@@ -127,10 +147,8 @@ def main():
             print('%d/%d, depth: %d, %d rays/s elapsed: %.2f s, eta: %.1f min' % (
                 done, total, scene.max_bounces - 1, int(n_rays * per_second),
                 elapsed, (total - done) / per_second / 60.0))
-        if done >= next_refresh or done == total:
+        if refresh:
             imgdata = whole_image()
-            step = args.itr_per_refresh if done >= args.itr_per_refresh else max(1, args.itr_per_refresh // 10)
-            next_refresh = min(done + step, total)
             if rank != 0:
                 continue
             print('image mean:', np.mean(np.ravel(imgdata)))
