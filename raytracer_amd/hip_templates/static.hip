@@ -113,6 +113,21 @@ CLR_FN vec3 apply_affine_transform(const float4* m, vec3 v) {
     return apply_linear_transform(m, v) + make_vec3(m[3]);
 }
 
+// Conservative miss test for the unit sphere from the un-normalised ray in tracer coordinates
+// (Sphere.can_hit_expression): false only where the reference's test - normalise the ray, then
+// half_b = -u.o <= 0 or disc = half_b^2 - |o|^2 + 1 < 0 - ends without a hit whatever its
+// roundings (eps = 2^-24; the reference's u.o is within 7 eps |o| of d.o / |d| and its disc within
+// 20 eps (|o|^2 + 1) of the exact one; the quantities below carry errors of 3.1 eps |d||o| and
+// 16 eps |d|^2 (|o|^2 + 1); the thresholds leave a factor of two: DESIGN section 3.1).
+// Origins on or inside the sphere, NaNs and infinities take the full test.
+CLR_FN bool clr_unit_sphere_may_be_hit(const vec3 o, const vec3 d) {
+    const float od = dot(o, d), oo = dot(o, o), dd = dot(d, d);
+    if (!(oo > 1.0f)) return true;
+    const bool heading_away = od > 0.0f && od * od > 0x1p-38f * (dd * oo);
+    const bool passing_by = od * od - dd * (oo - 1.0f) < -0x1p-18f * (dd * (oo + 1.0f));
+    return !(heading_away || passing_by);
+}
+
 // ---- quaternions (static.cl:87-101): x = real part
 CLR_FN vec4 quaternion_mult(vec4 q1, vec4 q2) {
     vec3 v1 = make_vec3(q1.y, q1.z, q1.w), v2 = make_vec3(q2.y, q2.z, q2.w);
