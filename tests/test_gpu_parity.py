@@ -815,3 +815,64 @@ def test_launch_chains_on_slices_of_the_frame_change_no_pixel(rng_mode):
     # a frame too small to cut stays on one stream
     small = Renderer(load_scene('scene-dev', (64, 48)), seed=9, overlap_parts=4)
     assert small.part_bounds() == [0, 64 * 48]
+
+
+def test_sphere_miss_test_agrees_with_the_full_test_on_grazing_rays():
+    """Sphere.can_hit_expression (static.hip, clr_unit_sphere_may_be_hit) drops a ray before the
+    normalisation only where the full test cannot find a hit.  Rays aimed at the silhouette of
+    three spheres (one of them scaled to an ellipsoid) within 0, +-1e-7 ... +-1e-3 radii of the
+    tangent, and rays that leave at right angles to the line to the centre, +- the same: first-hit
+    object, sub-object, distance and normal equal the oracle's full test bit for bit."""
+    from oracle import oracle
+    from raytracer_amd.objects import Sphere
+    from raytracer_amd.scenes.default_scenes import BoxScene
+    s = BoxScene()
+    s.image.size = (256, 96)
+    egg = Sphere((0.4, 1.0, 0.6), 0.3)
+    egg.linear_transform(scaling=(1, 1, 2))
+    bodies = [(np.array((-1.0, 0.5, 1.0)), 0.7, Sphere((-1.0, 0.5, 1.0), 0.7)),
+              (np.array((1.5, 2.0, 2.5)), 0.05, Sphere((1.5, 2.0, 2.5), 0.05)),
+              (np.array((0.4, 1.0, 0.6)), 0.3, egg)]
+    for _, _, tracer in bodies:
+        s.add_object(tracer, 'white')
+    r = Renderer(s, seed=2, split_passes=False)
+    origin = np.array(s.camera_position, dtype=np.float64)
+    rng = np.random.RandomState(77)
+    offsets = np.concatenate([[0.0], np.ravel([[d, -d] for d in (1e-7, 3e-7, 1e-6, 1e-5, 1e-4, 1e-3)])])
+    rays = []
+    while len(rays) < r.n_pixels:
+        centre, radius, _ = bodies[len(rays) % 3]
+        to_centre = centre - origin
+        dist = np.linalg.norm(to_centre)
+        axis = to_centre / dist
+        side = np.cross(axis, rng.normal(size=3))
+        side /= np.linalg.norm(side)
+        delta = offsets[rng.randint(len(offsets))]
+        if len(rays) % 2:
+            # tangent to the sphere (for the ellipsoid: near its silhouette), moved by delta radii
+            sin_a = min(radius * (1.0 + delta) / dist, 1.0)
+            direction = axis * np.sqrt(1.0 - sin_a ** 2) + side * sin_a
+        else:
+            # at right angles to the line to the centre, tilted by delta: heading away or not
+            direction = side + axis * delta
+        rays.append(direction / np.linalg.norm(direction))
+    cam = np.zeros((r.n_pixels, 4), dtype=np.float32)
+    cam[:, :3] = np.array(rays)[:r.n_pixels]
+    r.host_cam = cam
+    r.cam.set(cam)
+    tape = r.make_tape(0, 1)
+    tape[0][0, 0:3, :] = 0.0
+    tape[0][0, 0:3, 0:3] = np.eye(3)                  # no jitter: the crafted directions as they are
+    tape[0][0, 3, :] = 0.0
+    tape[0][0, 4, 0:3] = origin
+    ids, t, normal = r.first_hit(tape)
+    oids, ot, onormal = oracle.OracleScene(r).first_hit(tape)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(normal), bits(onormal))
+    hit = np.isin(oids[:, 0], [len(s.objects) - 2, len(s.objects) - 1, len(s.objects)])
+    assert 0.15 < hit.mean() < 0.6, hit.mean()         # the family straddles the silhouettes
+    # and the rest of the path: a few passes of the full estimator on the same rays
+    more = r.make_tape(1, 3)
+    r.render_tape(more)
+    oimg, _, _ = oracle.OracleScene(r).render(more)
+    assert np.array_equal(bits(r.img.get()), bits(oimg))
