@@ -113,6 +113,21 @@ CLR_FN vec3 apply_affine_transform(const float4* m, vec3 v) {
     return apply_linear_transform(m, v) + make_vec3(m[3]);
 }
 
+// HalfSpace.can_hit_expression, second part: may the plane x = 0 be reached before `limit` (the
+// closest hit so far / the light point)?  The reference's distance is -o.x / (l.x / len) / len with
+// one and the same rounded len: -o.x / l.x times three roundings, within 3.1 * 2^-24 of it, and it
+// counts only if it is below `limit`.  With p = limit |l.x| (one rounding), |o.x| >= p (1 + 2^-20)
+// (one more) puts the exact quotient at least 14 * 2^-24 above `limit`: the reference's value is not
+// below it.  Where p or l.x is so small that a rounding may be a denormal's, the full test decides.
+CLR_FN bool clr_plane_before(const float o_x, const float l_x, const float limit) {
+    const float p = limit * fabsf(l_x);
+    // both p and |l.x| above 2^-100: one unsigned comparison of the smaller bit pattern (a NaN's
+    // pattern is large and fails the comparison that follows)
+    const uint smaller = min(__float_as_uint(p), __float_as_uint(fabsf(l_x)));
+    const bool certainly_beyond = (smaller > 0x0D800000u) & (fabsf(o_x) >= p * 1.00000095f);
+    return !certainly_beyond;
+}
+
 // Conservative miss test for the unit sphere from the un-normalised ray in tracer coordinates
 // (Sphere.can_hit_expression): false only where the reference's test - normalise the ray, then
 // half_b = -u.o <= 0 or disc = half_b^2 - |o|^2 + 1 < 0 - ends without a hit whatever its

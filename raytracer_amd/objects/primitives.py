@@ -58,8 +58,11 @@ class HalfSpace(Tracer):
     # the current distance) or a NaN.  About half of the walls of a room drop out this way, and
     # neighbouring rays agree on which, so whole waves skip the test.
     # (bitwise operators: four compares and three mask operations, no short-circuit branches)
-    can_hit_expression = ('((local_pos.x > 0.0f) & (local_ray.x < 0.0f)) | '
-                          '((local_pos.x < 0.0f) & (local_ray.x > 0.0f))')
+    # Second condition: the plane is not certainly beyond the distance that counts - the closest
+    # hit so far, or the light point (static.hip, clr_plane_before).
+    can_hit_expression = ('(((local_pos.x > 0.0f) & (local_ray.x < 0.0f)) | '
+                          '((local_pos.x < 0.0f) & (local_ray.x > 0.0f))) & '
+                          'clr_plane_before(local_pos.x, local_ray.x, isec_dist)')
 
     def __init__(self, normal, h):
         Tracer.__init__(self)

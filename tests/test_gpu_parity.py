@@ -869,10 +869,49 @@ def test_sphere_miss_test_agrees_with_the_full_test_on_grazing_rays():
     oids, ot, onormal = oracle.OracleScene(r).first_hit(tape)
     assert np.array_equal(ids, oids)
     assert np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(normal), bits(onormal))
-    hit = np.isin(oids[:, 0], [len(s.objects) - 2, len(s.objects) - 1, len(s.objects)])
+    tracers = [tracer for _, _, tracer in bodies]
+    hit = np.isin(oids[:, 0], [i + 1 for i, obj in enumerate(s.objects) if obj.tracer in tracers])
     assert 0.15 < hit.mean() < 0.6, hit.mean()         # the family straddles the silhouettes
     # and the rest of the path: a few passes of the full estimator on the same rays
     more = r.make_tape(1, 3)
     r.render_tape(more)
     oimg, _, _ = oracle.OracleScene(r).render(more)
     assert np.array_equal(bits(r.img.get()), bits(oimg))
+
+
+def test_plane_distance_test_agrees_with_the_full_test_on_near_ties():
+    """HalfSpace.can_hit_expression, second part (static.hip, clr_plane_before): a plane is dropped
+    before the ray is normalised only where the full test cannot put it below the distance that
+    counts.  Two parallel tilted planes whose offsets differ by 0, +-1, +-2, +-4 ... units in the
+    last place, in either object order: which of the two a ray hits first (and at which distance)
+    equals the oracle's full test bit for bit over a frame of rays, and so does a rendered image
+    (the same planes between the hit points and the light)."""
+    from oracle import oracle
+    from raytracer_amd.objects import HalfSpace, Sphere
+    from raytracer_amd.scenes.default_scenes import BoxScene
+    base = np.float32(2.0)
+    for ulps in (0, 1, -1, 2, -4, 16, -64):
+        other = float(np.nextafter(base, np.float32(np.inf if ulps > 0 else -np.inf)) if abs(ulps) == 1
+                      else base + np.float32(ulps) * np.spacing(base))
+        for swap in (False, True):
+            s = BoxScene()
+            s.image.size = (128, 64)
+            s.get_object('light').bidirectional_light = True
+            offsets = (other, float(base)) if swap else (float(base), other)
+            pair = [s.add_object(HalfSpace((0.3, 1.0, 0.2), h), 'white') for h in offsets]
+            s.add_object(Sphere((0.0, -3.0, 0.8), 0.4), 'white')
+            r = Renderer(s, seed=6, split_passes=False)
+            pair_ids = [s.objects.index(obj) + 1 for obj in pair]      # the renderer groups objects by class
+            tape = r.make_tape(0, 3)
+            ids, t, normal = r.first_hit(tape)
+            osc = oracle.OracleScene(r)
+            oids, ot, onormal = osc.first_hit(tape)
+            assert np.array_equal(ids, oids), (ulps, swap)
+            assert np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(normal), bits(onormal)), (ulps, swap)
+            planes = np.isin(oids[:, 0], pair_ids)
+            assert planes.mean() > 0.3, (planes.mean(), np.unique(oids[:, 0], return_counts=True))
+            if abs(ulps) >= 16:       # far enough apart for one plane to win everywhere
+                assert len(set(oids[planes, 0].tolist())) == 1
+            r.render_tape(tape)
+            oimg, _, _ = osc.render(tape)
+            assert np.array_equal(bits(r.img.get()), bits(oimg)), (ulps, swap)
