@@ -113,6 +113,17 @@ CLR_FN clr_direction clr_make_direction(vec3 v, clr_guard_spec &g) {
     return r;
 }
 
+// An object's local ray direction: normalised here, or - bit 12 of the object's skip mask: its
+// local ray IS the world ray (identity linear part) - the normalisation of the world ray that
+// the sweep made once for all such objects.  The same computation on the same bits either way.
+CLR_FN clr_direction clr_direction_of(vec3 v, const clr_direction &, const int, const clr_guard_safe &g) {
+    return clr_make_direction(v, g);
+}
+CLR_FN clr_direction clr_direction_of(vec3 v, const clr_direction &world, const int skip, clr_guard_spec &g) {
+    if (skip & (1 << 12)) return world;
+    return clr_make_direction(v, g);
+}
+
 // upper bound of a direction's length and of a distance along it (t <= 0: no hit, not divided)
 CLR_FN void clr_guard_upper(const clr_direction &, float, const clr_guard_safe &) {}
 CLR_FN void clr_guard_upper(const clr_direction &dir, float t, clr_guard_spec &g) {

@@ -112,6 +112,12 @@ CLR_FN void clr_closest_hit(const vec3 pos, const vec3 ray, float &isec_dist, ui
     const uint inside, const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
     CLR_G &clr_g)
 {
+    // the normalised world ray, shared by the objects whose local ray it is (clr_direction_of)
+### if renderer.shares_world_direction
+    const clr_direction world_dir = clr_make_direction(ray, clr_g);
+### else
+    const clr_direction world_dir = {};
+### endif
 ### for tracer, count, offset in renderer.object_groups
 ### set group = loop.index0
 ### if renderer.bake_parameters
@@ -119,14 +125,14 @@ CLR_FN void clr_closest_hit(const vec3 pos, const vec3 ray, float &isec_dist, ui
     {{ tracer.tracer_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject,
         last_whichobject, last_which_subobject, inside, vector_data, integer_data,
         {{ offset+1+i }}, clr_params + {{ renderer.group_param_base[group] + i*renderer.group_param_stride[group] }},
-        {{ renderer.affine_skip_mask(offset+i) }}, clr_g);
+        {{ renderer.affine_skip_mask(offset+i) }}, world_dir, clr_g);
     ### endfor
 ### else
     #pragma unroll {{ [count, 8]|min }}
     for (int i = 0; i < {{ count }}; ++i)
         {{ tracer.tracer_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject,
             last_whichobject, last_which_subobject, inside, vector_data, integer_data,
-            {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[group] }} + i*{{ renderer.group_param_stride[group] }}, 0, clr_g);
+            {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[group] }} + i*{{ renderer.group_param_stride[group] }}, 0, world_dir, clr_g);
 ### endif
 ### endfor
 }
@@ -173,6 +179,11 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
     const float isec_dist = light_dir.len;
     const vec3 ray = light_dir.unit;
     float shadow_mask = 1.0f;
+### if renderer.shares_world_direction
+    const clr_direction world_dir = clr_make_direction(ray, clr_g);
+### else
+    const clr_direction world_dir = {};
+### endif
 ### for tracer, count, offset in renderer.object_groups
 ### set group = loop.index0
 ### if renderer.bake_parameters
@@ -182,7 +193,7 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
         {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,
             shadow_mask, vector_data, integer_data,
             {{ offset+1+i }}, clr_params + {{ renderer.group_param_base[group] + i*renderer.group_param_stride[group] }},
-            {{ renderer.affine_skip_mask(offset+i) }}, clr_g);
+            {{ renderer.affine_skip_mask(offset+i) }}, world_dir, clr_g);
     ### endfor
 ### else
     #pragma unroll {{ [count, 8]|min }}
@@ -190,7 +201,7 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
         if ({{ offset+1 }} + i != light_id && shadow_mask != 0.0f)
             {{ tracer.shadow_kernel_name }}(pos, ray, isec_dist, whichobject, which_subobject, inside,
                 shadow_mask, vector_data, integer_data,
-                {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[group] }} + i*{{ renderer.group_param_stride[group] }}, 0, clr_g);
+                {{ offset+1 }} + i, clr_params + {{ renderer.group_param_base[group] }} + i*{{ renderer.group_param_stride[group] }}, 0, world_dir, clr_g);
 ### endif
 ### endfor
     return shadow_mask;

@@ -68,7 +68,7 @@ template<class CLR_G> CLR_FN void {{ obj.tracer_kernel_name }}(
     const vec3 pos, const vec3 ray, float &isec_dist, uint &whichobject, uint &which_subobject,
     const uint last_whichobject, const uint last_which_subobject, const uint inside,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-    const int object_id, const float4 *P, const int affine_skip, CLR_G &clr_g)
+    const int object_id, const float4 *P, const int affine_skip, const clr_direction &world_dir, CLR_G &clr_g)
 {
     const bool within = inside == (uint)object_id,
                on_surface = last_whichobject == (uint)object_id;
@@ -86,7 +86,7 @@ template<class CLR_G> CLR_FN void {{ obj.tracer_kernel_name }}(
         if ({{ obj.can_hit_expression }}) {
     ### endif
         // unit direction, stretch = |local_ray|; the four quotients by stretch share one reciprocal
-        const clr_direction dir = clr_make_direction(local_ray, clr_g);
+        const clr_direction dir = clr_direction_of(local_ray, world_dir, affine_skip, clr_g);
 
         {{ obj.tracer_function_name }}(
             local_pos, dir.unit, isec_dist*dir.len, &new_isec_dist, &cur_subobject,
@@ -120,7 +120,7 @@ template<class CLR_G> CLR_FN void {{ obj.shadow_kernel_name }}(
     const vec3 pos, const vec3 ray, const float isec_dist,
     const uint whichobject, const uint which_subobject, const uint inside, float &shadow_mask,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-    const int object_id, const float4 *P, const int affine_skip, CLR_G &clr_g)
+    const int object_id, const float4 *P, const int affine_skip, const clr_direction &world_dir, CLR_G &clr_g)
 {
     uint subobject = which_subobject;
     const bool within = inside == (uint)object_id,
@@ -137,7 +137,7 @@ template<class CLR_G> CLR_FN void {{ obj.shadow_kernel_name }}(
         if ({{ obj.can_hit_expression }}) {
     ### endif
         // unit direction, stretch = |local_ray|; the four quotients by stretch share one reciprocal
-        const clr_direction dir = clr_make_direction(local_ray, clr_g);
+        const clr_direction dir = clr_direction_of(local_ray, world_dir, affine_skip, clr_g);
 
         {{ obj.tracer_function_name }}(
             local_pos, dir.unit, isec_dist*dir.len, &new_isec_dist, &subobject,

@@ -293,7 +293,24 @@ class Renderer:
                     mask |= 1 << (3 * r + c)
             if rows[3][r] != 0.0:
                 mask |= 1 << (9 + r)
+        if self.shares_world_direction and self._identity_linear(object_index):
+            mask |= 1 << 12
         return mask
+
+    def _identity_linear(self, object_index):
+        end = self.object_param_base[object_index] + self.scene.objects[object_index].tracer.param_slots
+        return bool(np.array_equal(self.param_table[end - 4:end - 1, :3], np.eye(3, dtype=np.float32)))
+
+    @property
+    def shares_world_direction(self):
+        """Objects whose inverse transform has an identity linear part see the world ray itself as
+        their local ray: its normalisation (the reference's per-object first step) is the same
+        computation for all of them and is done once per sweep when at least two such objects
+        exist (bit 12 of the affine skip mask; speculative arithmetic with baked parameters only,
+        where the products with the literal 1 and 0 coefficients fold away)."""
+        if not (self.bake_parameters and self.speculate):
+            return False
+        return sum(self._identity_linear(i) for i in range(len(self.scene.objects))) >= 2
 
     def param_table_literals(self):
         """The parameter table as exact C++17 hexadecimal float literals, row by row."""
