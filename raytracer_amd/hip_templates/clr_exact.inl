@@ -113,6 +113,36 @@ CLR_FN clr_direction clr_make_direction(vec3 v, clr_guard_spec &g) {
     return r;
 }
 
+// ---- products with a direction vector some of whose components are known to be zero
+// (`zero` = clr_zero_mask of that vector: a constant after inlining where the parameters are baked
+// into the program, a wave-uniform value otherwise).  For finite v a
+// product with a zero is a zero and adding it changes nothing unless the whole sum is a zero
+// (whose sign may then differ, which a later sum with a non-zero term, a square or a comparison
+// cannot see).  The speculative version leaves those products out; the generic one evaluates
+// every term, in the reference's order (x + y) + z.
+CLR_FN int clr_zero_mask(const vec3 n) {
+    return (n.x == 0.0f ? 1 : 0) | (n.y == 0.0f ? 2 : 0) | (n.z == 0.0f ? 4 : 0);
+}
+CLR_FN float clr_dot_lit(const vec3 v, const vec3 n, const int, const clr_guard_safe &) {
+    return v.x * n.x + v.y * n.y + v.z * n.z;
+}
+CLR_FN float clr_dot_lit(const vec3 v, const vec3 n, const int zero, clr_guard_spec &) {
+    float r = 0.0f;
+    bool any = false;
+    if (!(zero & 1)) { r = v.x * n.x; any = true; }
+    if (!(zero & 2)) { r = any ? r + v.y * n.y : v.y * n.y; any = true; }
+    if (!(zero & 4)) { r = any ? r + v.z * n.z : v.z * n.z; }
+    return r;
+}
+// v - s * n (the part of v at right angles to a unit axis n, s = v . n)
+CLR_FN vec3 clr_reject_lit(const vec3 v, const float s, const vec3 n, const int, const clr_guard_safe &) {
+    return make_vec3(v.x - s * n.x, v.y - s * n.y, v.z - s * n.z);
+}
+CLR_FN vec3 clr_reject_lit(const vec3 v, const float s, const vec3 n, const int zero, clr_guard_spec &) {
+    return make_vec3((zero & 1) ? v.x : v.x - s * n.x, (zero & 2) ? v.y : v.y - s * n.y,
+                     (zero & 4) ? v.z : v.z - s * n.z);
+}
+
 // An object's local ray direction: normalised here, or - bit 12 of the object's skip mask: its
 // local ray IS the world ray (identity linear part) - the normalisation of the world ray that
 // the sweep made once for all such objects.  The same computation on the same bits either way.

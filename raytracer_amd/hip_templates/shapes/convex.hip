@@ -84,8 +84,9 @@
 {#- ===== HalfSpaceComponent: normal . x <= h ============================================ -#}
 ### macro HalfSpaceComponent__tracer(obj)
     ### call tracer_component_function_base(obj)
-        float slope = dot(ray, normal);
-        float dist = dot(-origin, normal) + h;
+        const int zero_mask = clr_zero_mask(normal);
+        float slope = clr_dot_lit(ray, normal, zero_mask, clr_g);
+        float dist = clr_dot_lit(-origin, normal, zero_mask, clr_g) + h;
         dist = dist/slope;
         if (slope < 0) *t_enter = dist;
         else *t_exit = dist;
@@ -119,7 +120,8 @@
 
 ### macro LayerComponent__tracer(obj)
     ### call tracer_component_function_base(obj)
-        {{ slab_body('dot(ray, normal)', 'dot(-origin, normal)', 'h') }}
+        const int zero_mask = clr_zero_mask(normal);
+        {{ slab_body('clr_dot_lit(ray, normal, zero_mask, clr_g)', 'clr_dot_lit(-origin, normal, zero_mask, clr_g)', 'h') }}
     ### endcall
 ### endmacro
 
@@ -160,9 +162,10 @@
 
 ### macro CylinderComponent__tracer(obj)
     ### call tracer_component_function_base(obj)
-        float o_ax = dot(origin, axis), d_ax = dot(ray, axis);
-        vec3 o_perp = origin - o_ax*axis;
-        vec3 d_perp = ray - d_ax*axis;
+        const int zero_mask = clr_zero_mask(axis);
+        float o_ax = clr_dot_lit(origin, axis, zero_mask, clr_g), d_ax = clr_dot_lit(ray, axis, zero_mask, clr_g);
+        vec3 o_perp = clr_reject_lit(origin, o_ax, axis, zero_mask, clr_g);
+        vec3 d_perp = clr_reject_lit(ray, d_ax, axis, zero_mask, clr_g);
         float half_b = dot(d_perp, o_perp);
         float o_perp2 = dot(o_perp, o_perp);
         float d_perp2 = dot(d_perp, d_perp);
