@@ -72,9 +72,13 @@ def parse_args():
                     help='1/0: pass-split program (several lanes per pixel) on/off; default: on for small frames')
     ap.add_argument('--pass-groups', type=int, default=None,
                     help='pass-split program: lanes per pixel at least (default: 4 for mesh scenes, else 1)')
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--streams', default='auto',
                     help='launch chains: every step goes out as this many launches on slices of the frame, each '
-                         'slice on its own stream, so that one slice fills the GPU while another drains (1: one stream)')
+                         'slice on its own stream, so that one slice fills the GPU while another drains (1: one '
+                         'stream; auto: 2, and 1 for a pass-split program)')
+    ap.add_argument('--in-flight', default='auto',
+                    help='pass-split programs (small frames, meshes): this many steps log their addends at the '
+                         'same time, on streams and logs of their own; the sums are added in step order (auto: 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
@@ -191,7 +195,8 @@ def main():
                  build_options=args.build_options.split() if args.build_options else None,
                  bake_parameters=None if args.bake is None else bool(args.bake),
                  split_passes=None if args.split_passes is None else bool(args.split_passes),
-                 overlap_parts=args.streams, **shard.renderer_arguments())
+                 overlap_parts=args.streams if args.streams == 'auto' else int(args.streams),
+                 steps_in_flight=args.in_flight if args.in_flight == 'auto' else int(args.in_flight), **shard.renderer_arguments())
     if args.pass_groups:
         r.min_pass_groups = args.pass_groups
     shard.configure(r)                          # per-pixel random numbers are keyed by the GLOBAL pass index
@@ -265,6 +270,7 @@ def main():
                    'speculative_exact_arithmetic': bool(r.speculate),
                    'occupancy_hint': r.min_waves_per_simd,
                    'launches_per_step': len(r.part_bounds()) - 1,
+                   'steps_in_flight': r.steps_in_flight if r.split_passes else 1,
                    'kernel_registers': {key.lstrip('.'): value for key, value in getattr(r, 'kernel_metadata', {}).items()
                                         if key in ('.vgpr_count', '.sgpr_count', '.vgpr_spill_count',
                                                    '.sgpr_spill_count', '.private_segment_fixed_size',

@@ -81,7 +81,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         args.device = local_rank
     renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device, rng_mode=args.rng,
-                                      light_samples=args.light_samples, overlap_parts=2, **shard.renderer_arguments())
+                                      light_samples=args.light_samples, overlap_parts='auto', steps_in_flight='auto', **shard.renderer_arguments())
     shard.configure(renderer)
     # Timing the occupancy candidates costs six more program builds (about a minute).  Kernels of
     # analytic primitives run the same at every candidate; ray marchers and meshes differ by up

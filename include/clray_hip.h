@@ -164,6 +164,14 @@ typedef struct clr_render_args {
      * this call has the global index first_pass + j * pass_stride (0 is read as 1), so that every
      * GPU draws exactly the numbers a single GPU would draw for the same pass */
     int pass_stride;
+    /* pass-split programs, optional (NULL: as before): a stream whose work enqueued so far the
+     * second kernel of this call waits for, so that consecutive calls overlap.  A pixel's sums
+     * must be added in call order, but the first kernel of call k + 1 needs nothing of call k when
+     * it writes to another pass_log.  A caller that deals its calls out to D (stream, pass_log)
+     * pairs in turn and passes the previous call's stream here has up to D first kernels in
+     * flight and the additions in call order (call k + D follows call k on the same stream, so
+     * its log is free again); results do not change.  No counterpart in the reference. */
+    void *reduce_after;
 } clr_render_args;
 
 int clr_render_passes(clr_program *prog, const clr_render_args *args, void *stream,

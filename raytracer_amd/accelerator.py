@@ -37,7 +37,7 @@ class RenderArgs(ctypes.Structure):
                 ('rng_seed_lo', ctypes.c_uint), ('rng_seed_hi', ctypes.c_uint),
                 ('first_pass', ctypes.c_int), ('first_ray', ctypes.c_int),
                 ('pass_log', ctypes.c_void_p), ('pass_groups', ctypes.c_int),
-                ('pass_stride', ctypes.c_int)]
+                ('pass_stride', ctypes.c_int), ('reduce_after', ctypes.c_void_p)]
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)

@@ -573,6 +573,8 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     }
     else if (a->pass_groups != 0 || a->pass_log)
         return fail("clr_render_passes: pass_groups / pass_log given, but the program was not generated in pass-split mode");
+    if (a->reduce_after && (!prog->split_mode || static_log))
+        return fail("clr_render_passes: reduce_after is for pass-split programs with a pass_log of the caller's");
     if (a->n_passes == 0) { if (elapsed_ms) *elapsed_ms = 0.0f; return 0; }
     void *img = a->img;
     const void *cam = a->cam, *pt = a->pass_tape, *bt = a->bounce_tape, *mr = a->material_rows,
@@ -604,6 +606,11 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     hipStream_t s = (hipStream_t)stream;
     if (elapsed_ms) CLR_TRY(hipEventRecord(prog->ctx->ev_start, s));
     CLR_TRY(hipModuleLaunchKernel(render, grid[0], 1, 1, kBlock, 1, 1, 0, s, args, nullptr));
+    // the sums of a pixel are added in call order: the adding kernel waits for the previous call's
+    // on reduce_after, while the logging kernels of consecutive calls overlap (clray_hip.h)
+    if (a->reduce_after && a->reduce_after != stream) {
+        if (int rc = clr_stream_wait(prog->ctx, stream, a->reduce_after)) return rc;
+    }
     CLR_TRY(hipModuleLaunchKernel(prog->reduce_log, reduce_grid[0], 1, 1, kBlock, 1, 1, 0, s, reduce_args, nullptr));
     if (elapsed_ms) {
         CLR_TRY(hipEventRecord(prog->ctx->ev_stop, s));

@@ -74,7 +74,7 @@ class Renderer:
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
                  min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None,
-                 regenerate=None, light_samples=1, overlap_parts=1):
+                 regenerate=None, light_samples=1, overlap_parts=1, steps_in_flight=1):
         self.scene = scene
         # Launch chains on slices of the frame: with k > 1 every launch of
         # render_resident goes out as k launches, one per contiguous slice of the ray order, each
@@ -82,8 +82,16 @@ class Renderer:
         # slices overlap, so the blocks of one fill the GPU while the last blocks of another
         # drain.  No pixel changes (a pixel belongs to one slice).  1 = everything on the caller's
         # stream, as the reference's single queue.
-        self.overlap_parts = max(1, int(overlap_parts))
+        self._overlap_parts = overlap_parts
         self._part_streams = []
+        # Pass-split programs only: up to d launches of render_resident log their addends at the
+        # same time (d logs, d streams per slice); the sums are still added in launch order on the
+        # slice's stream, so no pixel changes.  Small frames are bound by their longest path:
+        # launch k + 1 fills the lanes that the last paths of launch k leave idle.
+        # 'auto' for both: what measured best - two slices for a one-lane program,
+        # one slice and two steps in flight for a pass-split one.
+        self._steps_in_flight = steps_in_flight
+        self._launch_counter = 0
         # next-event estimation with k points of the segment's light instead of one (no
         # counterpart in the reference, k = 1 is its estimator).  The light is still picked once per
         # segment; its contribution is the mean over the k points, each with its own visibility test.
@@ -147,7 +155,7 @@ class Renderer:
         self.split_passes = bool(split_passes)
         # lanes per pixel a pass-split launch uses at least (more on small frames, pass_groups_for)
         self.min_pass_groups = 4 if self.has_mesh else 1
-        self._pass_log = None
+        self._pass_logs = {}
         # optional occupancy hint for the render kernel (second __launch_bounds__ argument)
         self.min_waves_per_simd = min_waves_per_simd
         # small scenes: bake the per-object parameters into the program text as literals
@@ -583,24 +591,57 @@ class Renderer:
                 # a slice's part of the addend log: the log is (pass, float, pixel) with the slice's
                 # own pixel count as the stride, so the slices' logs lie one after the other
                 args.pass_log += 4 * count * (1 + 6 * self.scene.max_bounces) * lo
+            if after is not None:
+                args.reduce_after = after
             return self.acc.render_passes(args, stream=on_stream, timed=timed_launch, static_log=static_log)
 
-        split = self._split_args(count, static_log=static_log)
-        parts = self.part_bounds() if stream is None and not static_log else [0, self.n_pixels]
-        if len(parts) == 2:
+        after = None
+        chained = stream is None and not static_log
+        in_flight = self.steps_in_flight if chained and self.split_passes else 1
+        slot = self._launch_counter % in_flight
+        self._launch_counter += 1
+        split = self._split_args(count, static_log=static_log, slot=slot)
+        parts = self.part_bounds() if chained else [0, self.n_pixels]
+        if len(parts) == 2 and in_flight == 1:
             return launch(0, self.n_pixels, stream, timed)
-        while len(self._part_streams) < len(parts) - 1:
+        # pass-split program with several steps in flight: launch k + 1 logs into another buffer on
+        # another stream while launch k is still running; its sums are added after launch k's
+        # (clr_render_args.reduce_after).  Stream [slot][slice].
+        n_slices = len(parts) - 1
+        while len(self._part_streams) < in_flight * n_slices:
             self._part_streams.append(self.acc.new_stream())
         if timed:
             self.acc.timer_begin()
-        for p in range(len(parts) - 1):
-            launch(parts[p], parts[p + 1], self._part_streams[p], False)
+        for p in range(n_slices):
+            if in_flight > 1:
+                after = self._part_streams[(slot - 1) % in_flight * n_slices + p]
+            launch(parts[p], parts[p + 1], self._part_streams[slot * n_slices + p], False)
         if timed:
             self.join_parts()
             ms = self.acc.timer_end()
             self.acc._record('clr_render', ms * 1e-3, ms * 1e-3)
             return ms
         return None
+
+    @property
+    def overlap_parts(self):
+        if self._overlap_parts == 'auto':
+            return 1 if self.split_passes else 2
+        return max(1, int(self._overlap_parts))
+
+    @overlap_parts.setter
+    def overlap_parts(self, value):
+        self._overlap_parts = value
+
+    @property
+    def steps_in_flight(self):
+        if self._steps_in_flight == 'auto':
+            return 2 if self.split_passes else 1
+        return max(1, int(self._steps_in_flight))
+
+    @steps_in_flight.setter
+    def steps_in_flight(self, value):
+        self._steps_in_flight = value
 
     def part_bounds(self):
         """Ray indices at which the frame is cut into overlap_parts slices (multiples of the block size)."""
@@ -622,18 +663,22 @@ class Renderer:
             return None
         return log_passes_limit(self.n_pixels, self.scene.max_bounces)
 
-    def _split_args(self, n_passes, debug=False, static_log=False):
-        """The pass-split fields of clr_render_args (empty for a one-lane-per-pixel program)."""
+    def _split_args(self, n_passes, debug=False, static_log=False, slot=0):
+        """The pass-split fields of clr_render_args (empty for a one-lane-per-pixel program).
+        slot: which of the steps_in_flight addend logs to use."""
         if not self.split_passes:
             return {}
         groups = 1 if debug else pass_groups_for(self.n_pixels, n_passes, self.min_pass_groups)
         if static_log:
             return dict(pass_log=None, pass_groups=groups)
         floats = 1 + 6 * self.scene.max_bounces
-        if self._pass_log is None or self._pass_log.shape[0] < n_passes:
-            self._pass_log = None          # release before growing
-            self._pass_log = self.acc.new_array((max(n_passes, 1), floats, self.n_pixels), np.float32)
-        return dict(pass_log=self._pass_log.ptr, pass_groups=groups)
+        log = self._pass_logs.get(slot)
+        if log is None or log.shape[0] < n_passes:
+            if log is not None:
+                self.acc.finish()          # a launch in flight may still use it
+            self._pass_logs[slot] = log = None          # release before growing
+            self._pass_logs[slot] = log = self.acc.new_array((max(n_passes, 1), floats, self.n_pixels), np.float32)
+        return dict(pass_log=log.ptr, pass_groups=groups)
 
     def _rng_args(self, first_pass):
         """The per-pixel random number fields of clr_render_args."""

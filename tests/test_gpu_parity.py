@@ -812,6 +812,25 @@ def test_launch_chains_on_slices_of_the_frame_change_no_pixel(rng_mode):
     for first in (0, 4, 8):
         r.render_resident(first, 4, timed=False)
     assert np.array_equal(bits(r.img.get()), bits(want))
+    # ... and with several launches in flight: launch k + 1 logs into another buffer on another
+    # stream while launch k runs, the sums are added in launch order (clr_render_args.reduce_after)
+    for parts, in_flight, steps in ((2, 3, ((0, 2), (2, 2), (4, 1), (5, 3), (8, 4))), (1, 2, ((0, 4), (4, 4), (8, 4)))):
+        r = Renderer(load_scene('scene-dev', (320, 240)), seed=9, rng_mode=rng_mode, split_passes=True,
+                     overlap_parts=parts, steps_in_flight=in_flight)
+        r.upload_tape(tape)
+        for first, count in steps:
+            r.render_resident(first, count, timed=False)
+        assert np.array_equal(bits(r.img.get()), bits(want)), (parts, in_flight)
+        assert len(r._part_streams) == parts * in_flight and len(r._pass_logs) == in_flight
+        r.img.fill(0)
+        assert r.render_resident(0, 4) > 0
+    # a one-lane program has no log: the option changes nothing
+    r = Renderer(load_scene('scene-dev', (320, 240)), seed=9, rng_mode=rng_mode, split_passes=False,
+                 overlap_parts=2, steps_in_flight=3)
+    r.upload_tape(tape)
+    for first in (0, 4, 8):
+        r.render_resident(first, 4, timed=False)
+    assert np.array_equal(bits(r.img.get()), bits(want)) and len(r._part_streams) == 2
     # a frame too small to cut stays on one stream
     small = Renderer(load_scene('scene-dev', (64, 48)), seed=9, overlap_parts=4)
     assert small.part_bounds() == [0, 64 * 48]

@@ -21,7 +21,7 @@ HINT=$(grep -o '"occupancy_hint": [0-9a-z]*' $OUT/plain.log | tail -1 | sed 's/.
 CHAINS="$BENCH --occupancy-hint $HINT"
 # counters are collected per launch with the kernels serialised: one launch per step there
 # (--streams 1); the launch chains of the default run get a kernel trace of their own
-BENCH="$BENCH --occupancy-hint $HINT --streams 1"
+BENCH="$BENCH --occupancy-hint $HINT --streams 1 --in-flight 1"
 timeout -k 10 200 $BENCH > $OUT/plain_hint.log 2>&1 || { echo plain run with hint failed; tail -5 $OUT/plain_hint.log; exit 1; }
 echo store filled: $(ls $CLRAY_CACHE_DIR | wc -l) programs, occupancy hint $HINT
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
