@@ -123,23 +123,43 @@ def main():
                 next_refresh = min(at + step, total)
             yield at - n, n, refresh
 
-    # The random numbers of a batch are drawn on the host (the reference's generator, in its order):
-    # a helper thread draws batch i + 1 while the GPU renders batch i (the launch waits inside the
-    # library, outside the interpreter lock).
+    # The passes up to the next refresh form one interval: their random numbers are drawn on the
+    # host (the reference's generator, in its order) and made resident in one piece, and the
+    # interval's batches are launched back to back without a host wait in between - as launch
+    # chains on slices of the frame, or with two steps in flight for a pass-split program
+    # (Renderer.render_resident).  A helper thread draws interval i + 1 while the GPU renders
+    # interval i (the wait at the end of an interval happens outside the interpreter lock).
     from concurrent.futures import ThreadPoolExecutor
-    plan = list(schedule())
+    intervals, current = [], []
+    for first, n, refresh in schedule():
+        current.append((first, n))
+        if refresh:
+            intervals.append(current)
+            current = []
     helper = ThreadPoolExecutor(1)
-    drawn = helper.submit(renderer.make_tape, plan[0][0], plan[0][1]) if plan else None
-    for i, (done, n, refresh) in enumerate(plan):
+
+    def draw(interval):
+        return renderer.make_tape(interval[0][0], sum(n for _, n in interval))
+
+    drawn = helper.submit(draw, intervals[0]) if intervals else None
+    for i, interval in enumerate(intervals):
         # passes [done, done + n) of the global sequence; with the passes partition this rank
         # renders those whose index is rank modulo the number of GPUs
+        done, n = interval[0][0], sum(count for _, count in interval)
         tape = drawn.result()
-        if i + 1 < len(plan):
-            drawn = helper.submit(renderer.make_tape, plan[i + 1][0], plan[i + 1][1])
+        if i + 1 < len(intervals):
+            drawn = helper.submit(draw, intervals[i + 1])
         mine = shard.local_tape(tape) if shard.pass_stride == 1 else tuple(
             x[(shard.pass_offset - done) % world::world] if x is not None else None for x in tape)
-        if mine[0].shape[0]:
-            renderer.render_tape(mine, first_pass=done + (shard.pass_offset - done) % shard.pass_stride)
+        n_mine = mine[0].shape[0]
+        if n_mine:
+            renderer.upload_tape(mine, first_pass=done + (shard.pass_offset - done) % shard.pass_stride)
+            acc.timer_begin()
+            for first in range(0, n_mine, batch):
+                renderer.render_resident(first, min(batch, n_mine - first), timed=False)
+            renderer.join_parts()
+            seconds = acc.timer_end() * 1e-3          # waits for the interval's launches
+            acc._record('clr_render', seconds, seconds)
         done += n
         elapsed = time.time() - startup_time
         per_second = done / elapsed
@@ -147,6 +167,7 @@ def main():
             print('%d/%d, depth: %d, %d rays/s elapsed: %.2f s, eta: %.1f min' % (
                 done, total, scene.max_bounces - 1, int(n_rays * per_second),
                 elapsed, (total - done) / per_second / 60.0))
+        refresh = True
         if refresh:
             imgdata = whole_image()
             if rank != 0:
