@@ -586,3 +586,12 @@ def test_slices_of_the_frame_for_launch_chains():
         sizes = np.diff(cuts)
         assert sizes.max() - sizes.min() <= 512
     assert Renderer(load_scene('scene-dev', (320, 240)), device=False).part_bounds() == [0, 320 * 240]
+    # 'auto': two slices for a one-lane program, one slice and two steps in flight for a pass-split one
+    big = Renderer(load_scene('scene-dev', (1920, 1080)), device=False, overlap_parts='auto', steps_in_flight='auto')
+    small = Renderer(load_scene('scene-dev', (320, 240)), device=False, overlap_parts='auto', steps_in_flight='auto')
+    assert not big.split_passes and (big.overlap_parts, big.steps_in_flight) == (2, 1)
+    assert small.split_passes and (small.overlap_parts, small.steps_in_flight) == (1, 2)
+    plain = Renderer(load_scene('scene-dev', (320, 240)), device=False)
+    assert (plain.overlap_parts, plain.steps_in_flight) == (1, 1)
+    plain.steps_in_flight = 3
+    assert plain.steps_in_flight == 3

@@ -13,11 +13,18 @@ from raytracer_amd.renderer import Renderer
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'scene-dev'
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-r = Renderer(load_scene(name, (1920, 1080)), seed=0, split_passes=False)
+# optional: frame size WxH and "split" for the pass-split program (then only the distribution of
+# the block times is printed: blocks = 256 lanes of one pass group)
+size = tuple(int(v) for v in sys.argv[3].split('x')) if len(sys.argv) > 3 else (1920, 1080)
+split = len(sys.argv) > 4 and sys.argv[4] == 'split'
+r = Renderer(load_scene(name, size), seed=0, split_passes=split)
 r.tune_occupancy(passes=8)
 tape = r.make_tape(0, passes * 3)
 r.upload_tape(tape)
 n_blocks = (r.n_pixels + 255) // 256
+if split:
+    groups = r._split_args(passes)['pass_groups']
+    n_blocks = (((r.n_pixels + 63) // 64) * 64 * groups + 255) // 256
 
 
 def timed(label, rounds=6):
@@ -33,6 +40,12 @@ def timed(label, rounds=6):
 cycles = timed('natural order')
 print('block cycles: mean %.0f, std %.0f, min %.0f, max %.0f; sum / max = %.1f' %
       (cycles.mean(), cycles.std(), cycles.min(), cycles.max(), cycles.sum() / cycles.max()))
+if split:
+    clock = 2.4e6          # cycles per ms, nominal
+    print('pass groups %d, blocks %d; block ms: mean %.3f, median %.3f, 90%% %.3f, 99%% %.3f, max %.3f' % (
+        groups, n_blocks, cycles.mean() / clock, np.median(cycles) / clock, np.percentile(cycles, 90) / clock,
+        np.percentile(cycles, 99) / clock, cycles.max() / clock))
+    sys.exit(0)
 # longest first
 order = np.argsort(-cycles, kind='stable')
 rays = (order[:, None] * 256 + np.arange(256)[None, :]).ravel()
