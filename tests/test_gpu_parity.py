@@ -300,6 +300,29 @@ def test_4k_frame_first_hit_matches_oracle():
     assert np.isfinite(img).all() and img[:, :3].mean() > 0
 
 
+def test_4k_ray_marching_workload_matches_oracle():
+    """BASELINE config C5 at its real size (scene-marchers, 3840 x 2160, 16 passes per launch as
+    bench.py runs it): object ids of all 8.3 M primary rays equal the oracle's, distances within
+    1e-4 relative (marching loops with libm calls in user code: the tolerance of
+    test_ray_marching_scene_matches_oracle), and the sums of one 16-pass launch agree with the
+    oracle's on every 257th ray to 1e-4 relative RMSE."""
+    r, osc = make('scene-marchers', (3840, 2160))
+    tape = r.make_tape(0, 1)
+    ids, t, _ = r.first_hit(tape)
+    oids, ot, _ = osc.first_hit(tape)
+    assert np.array_equal(ids, oids), np.count_nonzero((ids != oids).any(axis=1))
+    assert np.all(np.abs(t - ot) <= 1e-4 * np.abs(ot))
+    tape = r.make_tape(1, 16)
+    r.upload_tape(tape)
+    r.render_resident(0, 16)
+    pixels = np.arange(0, r.n_pixels, 257)
+    oimg, _, _ = osc.render(tape, pixels=pixels)
+    img = r.img.get()[pixels]
+    assert np.isfinite(img).all()
+    rel = np.sqrt(np.mean((img[:, :3] - oimg[:, :3]) ** 2)) / np.sqrt(np.mean(oimg[:, :3] ** 2))
+    assert rel <= 1e-4, rel
+
+
 def test_run_time_parameter_table_bit_exact():
     """Scenes with many objects read their parameters from __constant__ memory filled at run
     time instead of baked literals; same bits either way."""
