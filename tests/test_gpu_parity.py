@@ -300,6 +300,24 @@ def test_4k_frame_first_hit_matches_oracle():
     assert np.isfinite(img).all() and img[:, :3].mean() > 0
 
 
+@pytest.mark.parametrize('name', ['scene-dev', 'scene-three-objects'])
+def test_bench_workload_at_1080p_bit_exact_on_a_subsample(name):
+    """BASELINE configs C3 / C2 as bench.py runs them: 1920 x 1080, 32 passes per step, two steps
+    back to back in the automatic launch pattern (two launch chains).  The sums of every 257th
+    ray equal the oracle's bit for bit (tape mode: a pixel's path depends on its camera ray and
+    the shared tape only)."""
+    from oracle import oracle
+    r = Renderer(load_scene(name, (1920, 1080)), seed=4, overlap_parts='auto', steps_in_flight='auto')
+    assert len(r.part_bounds()) == 3 and r.speculate
+    tape = r.make_tape(0, 64)
+    r.upload_tape(tape)
+    for step in range(2):
+        r.render_resident(32 * step, 32, timed=False)
+    pixels = np.arange(0, r.n_pixels, 257)
+    oimg, _, _ = oracle.OracleScene(r).render(tape, pixels=pixels)
+    assert np.array_equal(bits(r.img.get()[pixels]), bits(oimg))
+
+
 def test_4k_ray_marching_workload_matches_oracle():
     """BASELINE config C5 at its real size (scene-marchers, 3840 x 2160, 16 passes per launch as
     bench.py runs it): object ids of all 8.3 M primary rays equal the oracle's, distances within
