@@ -31,6 +31,16 @@ int check(hipError_t e, const char *what) {
 #define CLR_TRY(expr) do { if (int rc_ = check((expr), #expr)) return rc_; } while (0)
 
 const unsigned kBlock = 256;
+// development knob: threads per block of the render kernel (64, 128 or 256 = default); the kernels
+// index with blockDim, so results do not depend on it
+unsigned render_block() {
+    static const unsigned value = [] {
+        const char *e = getenv("CLR_RENDER_BLOCK");
+        const unsigned v = e ? (unsigned)atoi(e) : 0;
+        return (v == 64 || v == 128) ? v : kBlock;
+    }();
+    return value;
+}
 
 // ---- addend log of clr_render_passes_static_log: device memory the library holds from load to
 // exit so that the call itself allocates nothing.  On the host `scratch` is only a handle for
@@ -590,22 +600,23 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     int pass_stride = a->pass_stride > 0 ? a->pass_stride : 1;
     void *args[] = {&img, &cam, &pt, &bt, &mr, &vd, &id, &n_pixels, &n_passes, &regen, &dbg,
                     &seed_lo, &seed_hi, &first_pass, &first_ray, &pass_log, &pass_groups, &pass_stride};
-    const unsigned block[3] = {kBlock, 1, 1};
+    const unsigned rb = render_block();
+    const unsigned block[3] = {rb, 1, 1};
     if (!prog->split_mode) {
-        const unsigned grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
+        const unsigned grid[3] = {((unsigned)n_pixels + rb - 1) / rb, 1, 1};
         return launch(prog->ctx, render, grid, block, args, stream, elapsed_ms);
     }
     // pass-split program: n_pixels x pass_groups lanes write the log, then one lane per pixel sums it
     // whole waves per group, so that no wave straddles two groups (main.hip)
     const unsigned long long lanes = (((unsigned long long)n_pixels + 63) & ~63ull) * (unsigned)pass_groups;
     if (lanes > 0x7fffffffull) return fail("clr_render_passes: n_pixels x pass_groups is too large");
-    const unsigned grid[3] = {(unsigned)((lanes + kBlock - 1) / kBlock), 1, 1};
+    const unsigned grid[3] = {(unsigned)((lanes + rb - 1) / rb), 1, 1};
     const unsigned reduce_grid[3] = {((unsigned)n_pixels + kBlock - 1) / kBlock, 1, 1};
     const void *log_in = pass_log;
     void *reduce_args[] = {&img, &log_in, &n_pixels, &n_passes};
     hipStream_t s = (hipStream_t)stream;
     if (elapsed_ms) CLR_TRY(hipEventRecord(prog->ctx->ev_start, s));
-    CLR_TRY(hipModuleLaunchKernel(render, grid[0], 1, 1, kBlock, 1, 1, 0, s, args, nullptr));
+    CLR_TRY(hipModuleLaunchKernel(render, grid[0], 1, 1, rb, 1, 1, 0, s, args, nullptr));
     // the sums of a pixel are added in call order: the adding kernel waits for the previous call's
     // on reduce_after, while the logging kernels of consecutive calls overlap (clray_hip.h)
     if (a->reduce_after && a->reduce_after != stream) {
