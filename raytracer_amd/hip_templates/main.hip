@@ -432,7 +432,11 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
 ### endif
 ### if shader.rgb and renderer.materials_in_lds
     for (int i = threadIdx.x; i < {{ 5*(n_objects+1) }}; i += blockDim.x) {
-        clr_lds_material_colors[i] = clr_material_colors[i];
+        // .w = the probability of the stage that the colour belongs to (COLOR2PROB, shader.hip): a
+        // function of the material alone, divided once here instead of in every segment
+        float4 c = clr_material_colors[i];
+        c.w = COLOR2PROB(make_vec3(c));
+        clr_lds_material_colors[i] = c;
         clr_lds_material_scalars[i] = clr_material_scalars[i];
     }
     __syncthreads();

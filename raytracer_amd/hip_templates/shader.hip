@@ -14,9 +14,12 @@ typedef vec3 color_t;
 ### if renderer.materials_in_lds
 #define COLOR(prop, id) make_vec3(clr_lds_material_colors[(prop) + (id)])
 #define SCALAR(prop, id) clr_lds_material_scalars[(prop) + (id)]
+// COLOR2PROB of the same entry, computed when the table was copied to LDS (main.hip)
+#define STAGE_PROB(prop, id) clr_lds_material_colors[(prop) + (id)].w
 ### else
 #define COLOR(prop, id) make_vec3(clr_material_colors[(prop) + (id)])
 #define SCALAR(prop, id) clr_material_scalars[(prop) + (id)]
+#define STAGE_PROB(prop, id) COLOR2PROB(COLOR(prop, id))
 ### endif
 #define COLOR2PROB(color) (dot(color, make_vec3(1.0f, 1.0f, 1.0f))/3.0f)
 #define COLOR_ONE make_vec3(1.0f, 1.0f, 1.0f)
@@ -25,6 +28,7 @@ CLR_FN vec3 color_to_rgb(vec3 c, vec3 cmask) { return c; }
 typedef float color_t;
 #define COLOR(prop, id) material_scalars[(prop) + (id)]
 #define COLOR2PROB(color) (color)
+#define STAGE_PROB(prop, id) COLOR(prop, id)
 #define SCALAR(prop, id) material_scalars[(prop) + (id)]
 #define COLOR_ONE 1.0f
 CLR_FN vec3 color_to_rgb(float c, vec3 cmask) { return c * cmask; }
@@ -221,7 +225,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
     // ---- specular reflection (shader.cl:190-217)
     if (p >= 0.0f) {
         cur_col = m_reflection;
-        cur_prob = COLOR2PROB(cur_col);
+        cur_prob = STAGE_PROB(MAT_REFLECTION, s.whichobject);
         if (p < cur_prob) {
 ### if shader.rgb
             pipeline_color *= cur_col / cur_prob;
@@ -245,7 +249,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
     // ---- refraction / transparency (shader.cl:219-288)
     if (p >= 0.0f) {
         cur_col = m_transparency;
-        cur_prob = COLOR2PROB(cur_col);
+        cur_prob = STAGE_PROB(MAT_TRANSPARENCY, s.whichobject);
         if (p < cur_prob) {
 ### if shader.rgb
             pipeline_color *= cur_col / cur_prob;
@@ -298,7 +302,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
         s.suppress_emission = 0;
 ### endif
         cur_col = m_diffuse;
-        cur_prob = COLOR2PROB(cur_col);
+        cur_prob = STAGE_PROB(MAT_DIFFUSE, s.whichobject);
 
         if (cur_prob > 0.0f && s.diffusions_left > 0) {
             pipeline_color = pipeline_color * cur_col;
