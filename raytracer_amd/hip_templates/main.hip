@@ -32,6 +32,7 @@ __constant__ float clr_material_scalars[{{ 5*(n_objects+1) }}];
 // dependent gather per stage; from LDS that is ~60 cycles each instead of a trip to L2
 static __shared__ float4 clr_lds_material_colors[{{ 5*(n_objects+1) }}];
 static __shared__ float clr_lds_material_scalars[{{ 5*(n_objects+1) }}];
+static __shared__ float4 clr_lds_material_ratios[{{ 5*(n_objects+1) }}];      // colour / stage probability
 ### endif
 ### endif
 
@@ -437,6 +438,10 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
         float4 c = clr_material_colors[i];
         c.w = COLOR2PROB(make_vec3(c));
         clr_lds_material_colors[i] = c;
+        // what a specular stage multiplies the path's colour by when it is chosen (never read
+        // where the probability is zero: such a stage is not chosen)
+        const vec3 ratio = make_vec3(c) / c.w;
+        clr_lds_material_ratios[i] = make_float4(ratio.x, ratio.y, ratio.z, 0.0f);
         clr_lds_material_scalars[i] = clr_material_scalars[i];
     }
     __syncthreads();

@@ -16,10 +16,12 @@ typedef vec3 color_t;
 #define SCALAR(prop, id) clr_lds_material_scalars[(prop) + (id)]
 // COLOR2PROB of the same entry, computed when the table was copied to LDS (main.hip)
 #define STAGE_PROB(prop, id) clr_lds_material_colors[(prop) + (id)].w
+#define STAGE_RATIO(prop, id) make_vec3(clr_lds_material_ratios[(prop) + (id)])
 ### else
 #define COLOR(prop, id) make_vec3(clr_material_colors[(prop) + (id)])
 #define SCALAR(prop, id) clr_material_scalars[(prop) + (id)]
 #define STAGE_PROB(prop, id) COLOR2PROB(COLOR(prop, id))
+#define STAGE_RATIO(prop, id) (COLOR(prop, id) / COLOR2PROB(COLOR(prop, id)))
 ### endif
 #define COLOR2PROB(color) (dot(color, make_vec3(1.0f, 1.0f, 1.0f))/3.0f)
 #define COLOR_ONE make_vec3(1.0f, 1.0f, 1.0f)
@@ -224,11 +226,10 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 
     // ---- specular reflection (shader.cl:190-217)
     if (p >= 0.0f) {
-        cur_col = m_reflection;
         cur_prob = STAGE_PROB(MAT_REFLECTION, s.whichobject);
         if (p < cur_prob) {
 ### if shader.rgb
-            pipeline_color *= cur_col / cur_prob;
+            pipeline_color *= STAGE_RATIO(MAT_REFLECTION, s.whichobject);
 ### endif
             r -= 2*dot(r, n) * n;
             const float blur = m_reflection_blur;
@@ -248,11 +249,10 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 
     // ---- refraction / transparency (shader.cl:219-288)
     if (p >= 0.0f) {
-        cur_col = m_transparency;
         cur_prob = STAGE_PROB(MAT_TRANSPARENCY, s.whichobject);
         if (p < cur_prob) {
 ### if shader.rgb
-            pipeline_color *= cur_col / cur_prob;
+            pipeline_color *= STAGE_RATIO(MAT_TRANSPARENCY, s.whichobject);
 ### endif
             float dotp = dot(r, n);
             if (dotp > 0) { n = -n; dotp = -dotp; }
