@@ -108,6 +108,8 @@ def main(tag, key, src=None):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) < 2 or sys.argv[1].startswith('-'):
+        raise SystemExit('usage: summarize_profile.py <tag> [<workload key of profiles/pmc_traffic.json>] [<directory under gpurun_out>]')
     main(sys.argv[1] if len(sys.argv) > 1 else 'r01',
          sys.argv[2] if len(sys.argv) > 2 else 'scene-dev 1920x1080 p32 tape',
          sys.argv[3] if len(sys.argv) > 3 else None)
