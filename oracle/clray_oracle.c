@@ -1075,7 +1075,7 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
             material_view m = {sc, material_rows ? material_rows + (size_t)pass * row_len : 0, stride};
             for (int b = 0; b < sc->max_bounces; ++b) {
                 const bounce_sample B = rng
-                    ? draw_bounce(rng, (unsigned)(rng->first_ray + k), (unsigned)(rng->first_pass + pass * (rng->pass_stride > 0 ? rng->pass_stride : 1)), (unsigned)b,
+                    ? draw_bounce(rng, (unsigned)(rng->pixel_ids ? rng->pixel_ids[k] : rng->first_ray + k), (unsigned)(rng->first_pass + pass * (rng->pass_stride > 0 ? rng->pass_stride : 1)), (unsigned)b,
                                   b == sc->max_bounces - 1)
                     : load_bounce(bounce_tape + ((size_t)pass * sc->max_bounces + b) * bounce_record * 4);
                 float *d = dbg ? dbg + ((size_t)b * n_pixels + k) * ORC_DEBUG_RECORD * 4 : 0;

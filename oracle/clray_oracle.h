@@ -76,6 +76,7 @@ typedef struct orc_rng {
     int n_lights;
     const float *lights;                /* per light 8 floats: centre xyz, R, area, min distance, id (int bits), 0 */
     int pass_stride;                    /* global index of local pass j = first_pass + j * pass_stride; 0 = 1 */
+    const int *pixel_ids;               /* optional: global ray index of pixel k (a subset of the frame); NULL = first_ray + k */
 } orc_rng;
 
 #define ORC_PASS_RECORD 6

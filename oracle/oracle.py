@@ -67,7 +67,8 @@ _libs = {}
 class Rng(ctypes.Structure):
     _fields_ = [('seed_lo', ctypes.c_uint), ('seed_hi', ctypes.c_uint), ('first_pass', ctypes.c_int),
                 ('first_ray', ctypes.c_int), ('n_lights', ctypes.c_int),
-                ('lights', ctypes.POINTER(ctypes.c_float)), ('pass_stride', ctypes.c_int)]
+                ('lights', ctypes.POINTER(ctypes.c_float)), ('pass_stride', ctypes.c_int),
+                ('pixel_ids', ctypes.POINTER(ctypes.c_int))]
 
 
 def load(count_flops=False):
@@ -308,21 +309,26 @@ class OracleScene:
         """Add the passes of `tape` to img (n_pixels x 4 float32).  Returns (img, dump, flops).
         With a renderer in per-pixel random number mode the bounce part of the tape is None and
         `first_pass` is the global index of the tape's first pass.
-        pixels: ray indices to walk instead of the whole frame (tape mode only: there every pixel's
-        path depends on its camera ray and the shared tape alone); img then has one row per index."""
+        pixels: ray indices to walk instead of the whole frame (a pixel's path depends on its camera
+        ray and the shared tape alone, or, with per-pixel random numbers, on its own ray index as
+        well, which then keys its stream); img then has one row per index."""
         r = self.renderer
         passes, bounces, rows = tape
+        full = self.renderer
+        pixel_ids = None
         if pixels is not None:
-            assert getattr(r, 'rng_mode', 'tape') == 'tape' and not debug
+            assert not debug
             cam = np.ascontiguousarray(r.host_cam[pixels], np.float32)
-            full = self.renderer
-            r = type('Subset', (), dict(host_cam=cam, n_pixels=cam.shape[0], scene=full.scene, rng_mode='tape'))()
+            first_ray = full.ray_range[0] if getattr(full, 'ray_range', None) else 0
+            pixel_ids = np.ascontiguousarray(np.asarray(pixels, dtype=np.int64) + first_ray, dtype=np.int32)
+            r = type('Subset', (), dict(host_cam=cam, n_pixels=cam.shape[0], scene=full.scene))()
         rng = None
-        if getattr(r, 'rng_mode', 'tape') == 'philox':
-            lights = np.ascontiguousarray(r.light_table, np.float32)
-            rng = Rng(r.rng_seed & 0xffffffff, (r.rng_seed >> 32) & 0xffffffff, int(first_pass),
-                      r.ray_range[0] if r.ray_range else 0, r.n_lights, _fptr(lights),
-                      int(getattr(r, 'pass_stride', 1)))
+        if getattr(full, 'rng_mode', 'tape') == 'philox':
+            lights = np.ascontiguousarray(full.light_table, np.float32)
+            rng = Rng(full.rng_seed & 0xffffffff, (full.rng_seed >> 32) & 0xffffffff, int(first_pass),
+                      full.ray_range[0] if full.ray_range else 0, full.n_lights, _fptr(lights),
+                      int(getattr(full, 'pass_stride', 1)),
+                      pixel_ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int)) if pixel_ids is not None else None)
             bounces = np.zeros(1, np.float32)
         n = passes.shape[0]
         if img is None:
@@ -344,8 +350,12 @@ class OracleScene:
         self.last_mesh_bytes = lib.orc_last_mesh_bytes()
         return img, dump, flops.value
 
-    def first_hit(self, tape, n_threads=0):
+    def first_hit(self, tape, n_threads=0, pixels=None):
+        """pixels: ray indices to test instead of the whole frame (one row of results per index)."""
         r = self.renderer
+        if pixels is not None:
+            cam = np.ascontiguousarray(r.host_cam[pixels], np.float32)
+            r = type('Subset', (), dict(host_cam=cam, n_pixels=cam.shape[0]))()
         passes = np.ascontiguousarray(tape[0], np.float32)
         ids = np.zeros((r.n_pixels, 2), dtype=np.int32)
         t = np.zeros(r.n_pixels, dtype=np.float32)

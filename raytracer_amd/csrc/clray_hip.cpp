@@ -146,6 +146,8 @@ compact_scatter(const int * __restrict__ in, int * __restrict__ out, const size_
 struct clr_ctx {
     int device;
     hipEvent_t ev_start, ev_stop;         // around one timed launch
+    hipEvent_t ev_mid = nullptr;          // timed pass-split call: between the logging and the adding kernel
+    float last_render_ms = 0.0f, last_reduce_ms = 0.0f;
     hipEvent_t timer_start, timer_stop;   // clr_timer_begin / clr_timer_end
     unsigned *compact_work;               // clr_find_non_negative: per-tile counts / offsets, then the total
     size_t compact_tiles;                 // tiles the work buffer has room for
@@ -233,6 +235,7 @@ int clr_ctx_create(int device_index, clr_ctx **out) {
     ctx->compact_tiles = 0;
     if (int rc = check(hipEventCreate(&ctx->ev_start), "hipEventCreate")) { delete ctx; return rc; }
     if (int rc = check(hipEventCreate(&ctx->ev_stop), "hipEventCreate")) { delete ctx; return rc; }
+    if (int rc = check(hipEventCreate(&ctx->ev_mid), "hipEventCreate")) { delete ctx; return rc; }
     if (int rc = check(hipEventCreate(&ctx->timer_start), "hipEventCreate")) { delete ctx; return rc; }
     if (int rc = check(hipEventCreate(&ctx->timer_stop), "hipEventCreate")) { delete ctx; return rc; }
     *out = ctx;
@@ -244,6 +247,7 @@ int clr_ctx_destroy(clr_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     (void)hipEventDestroy(ctx->timer_start);
     (void)hipEventDestroy(ctx->timer_stop);
     if (ctx->compact_work) (void)hipFree(ctx->compact_work);
@@ -570,8 +574,10 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
         if (!prog->reduce_log || prog->log_floats < 1)
             return fail("clr_render_passes_static_log: the program lacks clr_reduce_log / clr_log_floats");
         if (a->pass_groups < 1) return fail("clr_render_passes_static_log: pass_groups must be >= 1");
-        const unsigned long long need = 4ull * (unsigned)a->n_passes * (unsigned)prog->log_floats * (unsigned)a->n_pixels;
-        if (need > CLR_STATIC_LOG_BYTES)
+        // by division: the product of three 32-bit factors can wrap 64 bits
+        const unsigned long long per_pass = 4ull * (unsigned)prog->log_floats * (unsigned)a->n_pixels;
+        const unsigned long long need = per_pass * (unsigned)a->n_passes;
+        if ((unsigned)a->n_passes > CLR_STATIC_LOG_BYTES / per_pass)
             return fail("clr_render_passes_static_log: the addend log of this call needs " + std::to_string(need) +
                         " bytes, the static log holds " + std::to_string(CLR_STATIC_LOG_BYTES) +
                         ": render fewer passes per call");
@@ -617,6 +623,7 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     hipStream_t s = (hipStream_t)stream;
     if (elapsed_ms) CLR_TRY(hipEventRecord(prog->ctx->ev_start, s));
     CLR_TRY(hipModuleLaunchKernel(render, grid[0], 1, 1, rb, 1, 1, 0, s, args, nullptr));
+    if (elapsed_ms) CLR_TRY(hipEventRecord(prog->ctx->ev_mid, s));
     // the sums of a pixel are added in call order: the adding kernel waits for the previous call's
     // on reduce_after, while the logging kernels of consecutive calls overlap (clray_hip.h)
     if (a->reduce_after && a->reduce_after != stream) {
@@ -627,10 +634,19 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
         CLR_TRY(hipEventRecord(prog->ctx->ev_stop, s));
         CLR_TRY(hipEventSynchronize(prog->ctx->ev_stop));
         CLR_TRY(hipEventElapsedTime(elapsed_ms, prog->ctx->ev_start, prog->ctx->ev_stop));
+        CLR_TRY(hipEventElapsedTime(&prog->ctx->last_render_ms, prog->ctx->ev_start, prog->ctx->ev_mid));
+        CLR_TRY(hipEventElapsedTime(&prog->ctx->last_reduce_ms, prog->ctx->ev_mid, prog->ctx->ev_stop));
     }
     return 0;
 }
 }  // namespace
+
+int clr_last_split_ms(clr_ctx *ctx, float *render_ms, float *reduce_ms) {
+    if (!ctx) return fail("null argument");
+    if (render_ms) *render_ms = ctx->last_render_ms;
+    if (reduce_ms) *reduce_ms = ctx->last_reduce_ms;
+    return 0;
+}
 
 int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms) {
     return render_passes(prog, a, stream, elapsed_ms, nullptr);

@@ -351,14 +351,32 @@ def torus_knot_mesh(n_u=1000, n_v=500, tube=0.45, bump=0.05):
     return vertices, faces
 
 
+def mesh_through_off_file(vertices, faces, path):
+    """the generated mesh "written as OFF and read back through
+    mesh_formats.read_off" - here through the native reader (csrc/mesh_io.cpp, which returns what
+    the reference's read_off returns, tests/test_mesh_io.py).  Returns (vertices, faces, seconds the
+    parse took).  %.9g round-trips binary32, so the arrays come back as they were."""
+    import time
+    from ..objects import meshes
+    meshes.write_off(path, vertices, faces)
+    t0 = time.perf_counter()
+    vertices, faces = meshes.read_mesh_file(path, 'off')
+    return vertices, faces, time.perf_counter() - t0
+
+
 def scene_mesh(n_u=1000, n_v=500, layout='flat', max_depth=None, max_faces_per_leaf=8,
-               max_steps=2000, material='white', pooled=None, overlap='sat'):
+               max_steps=2000, material='white', pooled=None, overlap='sat', mesh=None, via_off=None):
     """overlap: how the builder files faces under leaves - 'sat' (triangle against box, 3.0 leaf
     records per face on this mesh) or 'reference' (the reference's bounding-sphere rule, 12.7);
-    the hits are the same (tests/test_gpu_parity.py)."""
+    the hits are the same (tests/test_gpu_parity.py).
+    mesh: (vertices, faces) to use instead of the generated knot, e.g. what a mesh reader returned;
+    via_off: path of an OFF file the generated knot is written to and read back from through the
+    native reader before it is used (scene.mesh_parse_seconds then holds the parse time)."""
     s = BoxScene()
     s.get_object('light').bidirectional_light = True
-    vertices, faces = torus_knot_mesh(n_u, n_v)
+    vertices, faces = mesh if mesh is not None else torus_knot_mesh(n_u, n_v)
+    if via_off is not None:
+        vertices, faces, s.mesh_parse_seconds = mesh_through_off_file(vertices, faces, via_off)
     if max_depth is None:       # about one level per factor of 8 in the face count
         max_depth = int(min(10, max(3, np.ceil(np.log2(max(len(faces), 8)) / 3.0) + 2)))
     mesh = TriangleMesh(vertices, faces, auto_scale=True, center=(0, 0, 1), scale=1.0,

@@ -300,22 +300,30 @@ def test_4k_frame_first_hit_matches_oracle():
     assert np.isfinite(img).all() and img[:, :3].mean() > 0
 
 
-@pytest.mark.parametrize('name', ['scene-dev', 'scene-three-objects'])
-def test_bench_workload_at_1080p_bit_exact_on_a_subsample(name):
-    """BASELINE configs C3 / C2 as bench.py runs them: 1920 x 1080, 32 passes per step, two steps
-    back to back in the automatic launch pattern (two launch chains).  The sums of every 257th
-    ray equal the oracle's bit for bit (tape mode: a pixel's path depends on its camera ray and
-    the shared tape only)."""
+@pytest.mark.parametrize('name,rng_mode', [('scene-dev', 'tape'), ('scene-three-objects', 'tape'),
+                                           ('scene-dev-spectral', 'tape'), ('scene-dev', 'philox'),
+                                           ('scene-dev-spectral', 'philox')])
+def test_bench_workload_at_1080p_bit_exact_on_a_subsample(name, rng_mode):
+    """BASELINE configs C3 (RGB as shipped and the spectral variant) / C2 as bench.py runs them:
+    1920 x 1080, 32 passes per step, two steps back to back in the automatic launch pattern (two
+    launch chains), with the broadcast tape and with per-pixel Philox numbers (regenerating form).
+    The sums of every 257th ray equal the oracle's bit for bit (a pixel's path depends on its
+    camera ray and the shared tape only, or on its own stream, keyed by its ray index)
+    (/root/reference/shader.py:148-194 for the spectral rows)."""
     from oracle import oracle
-    r = Renderer(load_scene(name, (1920, 1080)), seed=4, overlap_parts='auto', steps_in_flight='auto')
-    assert len(r.part_bounds()) == 3 and r.speculate
+    r = Renderer(load_scene(name, (1920, 1080)), seed=4, overlap_parts='auto', steps_in_flight='auto',
+                 rng_mode=rng_mode)
+    assert len(r.part_bounds()) == 3 and r.speculate and r.regenerate == (rng_mode == 'philox')
+    assert r.shader.rgb == (name != 'scene-dev-spectral')
     tape = r.make_tape(0, 64)
     r.upload_tape(tape)
     for step in range(2):
         r.render_resident(32 * step, 32, timed=False)
     pixels = np.arange(0, r.n_pixels, 257)
     oimg, _, _ = oracle.OracleScene(r).render(tape, pixels=pixels)
-    assert np.array_equal(bits(r.img.get()[pixels]), bits(oimg))
+    img = r.img.get()
+    assert np.isfinite(img).all() and img[:, :3].std() > 0
+    assert np.array_equal(bits(img[pixels]), bits(oimg))
 
 
 def test_4k_ray_marching_workload_matches_oracle():
@@ -724,6 +732,44 @@ def test_one_million_triangles_pooled_per_lane_and_both_trees_agree():
         assert np.array_equal(ids, ids0) and np.array_equal(bits(t), bits(t0)) and np.array_equal(bits(n), bits(n0))
     assert images[0][:, :3].mean() > 0
     assert np.array_equal(bits(images[0]), bits(images[1]))
+
+
+def test_one_million_triangles_through_the_mesh_reader_against_the_oracle(tmp_path):
+    """BASELINE config C4 at its real size, fed the way SURVEY section 8d states it: the generated
+    1000 x 500 knot is written as an OFF file, parsed by the native reader (csrc/mesh_io.cpp, the
+    counterpart of /root/reference/mesh_formats.py:14-40), filed in the triangle-box tree and rendered
+    at 1920 x 1080 as bench.py does (pass-split program, two steps in flight).  On every 257th ray the
+    first-hit ids, distances and normals and the sums of two 2-pass steps equal, bit for bit, what
+    the oracle finds walking the reference's own tree (bounding-sphere rule) in the reference's
+    stream layout (/root/reference/cl_templates/objects/Octree.cl:32-168)."""
+    from oracle import oracle
+    from raytracer_amd.scenes.library import scene_mesh, torus_knot_mesh, mesh_through_off_file
+    vertices, faces = torus_knot_mesh(1000, 500)
+    v, f, seconds = mesh_through_off_file(vertices, faces, str(tmp_path / 'knot.off'))
+    print('parsed %d vertices, %d faces of OFF text in %.2f s' % (len(v), len(f), seconds))
+    assert v.dtype == np.float64 and np.array_equal(v.astype(np.float32), vertices) and np.array_equal(f, faces)
+    r = Renderer(scene_mesh(mesh=(v, f), layout='flat', overlap='sat'), seed=9,
+                 overlap_parts='auto', steps_in_flight='auto')
+    assert r.img_shape == (1080, 1920) and r.split_passes and r.steps_in_flight == 2
+    ref = Renderer(scene_mesh(mesh=(v, f), layout='stream', overlap='reference'), seed=9, device=False)
+    osc = oracle.OracleScene(ref)
+    tape = r.make_tape(0, 4)
+    one = tuple(x[:1] if x is not None else None for x in tape)
+    pixels = np.arange(0, r.n_pixels, 257)
+    ids, t, normal = r.first_hit(one)
+    oids, ot, onormal = osc.first_hit(one, pixels=pixels)
+    knot = [i + 1 for i, o in enumerate(r.scene.objects) if o.name == 'knot'][0]
+    on_knot = oids[:, 0] == knot
+    assert 0.05 < on_knot.mean() < 0.9 and len(np.unique(oids[on_knot, 1])) > 500
+    assert np.array_equal(ids[pixels], oids)
+    assert np.array_equal(bits(t[pixels]), bits(ot)) and np.array_equal(bits(normal[pixels]), bits(onormal))
+    r.upload_tape(tape)
+    for step in range(2):
+        r.render_resident(2 * step, 2, timed=False)
+    oimg, _, _ = osc.render(tape, pixels=pixels)
+    img = r.img.get()
+    assert np.isfinite(img).all() and img[:, :3].mean() > 0
+    assert np.array_equal(bits(img[pixels]), bits(oimg))
 
 
 def test_several_light_points_per_segment():

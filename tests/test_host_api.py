@@ -595,3 +595,21 @@ def test_slices_of_the_frame_for_launch_chains():
     assert (plain.overlap_parts, plain.steps_in_flight) == (1, 1)
     plain.steps_in_flight = 3
     assert plain.steps_in_flight == 3
+
+
+@pytest.mark.parametrize('rng_mode', ['tape', 'philox'])
+def test_oracle_pixel_subsets_equal_the_whole_frame(rng_mode):
+    """The oracle walks a subset of the frame's rays (`pixels=`) with the numbers those rays get in
+    the whole frame: shared tape, or per-pixel streams keyed by the ray's own index (also inside a
+    tile).  The full-size GPU parity tests rest on this."""
+    from oracle import oracle
+    from raytracer_amd.renderer import Renderer
+    for ray_range in (None, (256, 1024)):
+        r = Renderer(load_scene('scene-dev', (64, 48)), seed=3, rng_mode=rng_mode, device=False, ray_range=ray_range)
+        osc = oracle.OracleScene(r)
+        tape = r.make_tape(0, 3)
+        whole, _, _ = osc.render(tape, first_pass=5)
+        pixels = np.arange(1, r.n_pixels, 37)
+        part, _, _ = osc.render(tape, first_pass=5, pixels=pixels)
+        assert part.shape == (len(pixels), 4) and part[:, :3].max() > 0
+        assert np.array_equal(part.view(np.uint32), whole[pixels].view(np.uint32))
