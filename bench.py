@@ -25,8 +25,6 @@ sys.path.insert(0, ROOT)
 
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
 PEAK_FP32_VECTOR_TFLOPS = 157.3        # FP32 vector peak: one v_fma_f32 (2 flop) per lane per clock
-PEAK_FP32_NON_FMA_TOPS = 78.6          # ceiling for code without FMAs (one op per lane per clock): the
-                                       # parity build is compiled with -ffp-contract=off
 PEAK_HBM_GBS = 8000.0                  # HBM3E spec; ~6300 achievable (same guide)
 # algorithmic work is counted by the oracle's instrumented build over ALL timed passes, on every
 # FLOP_PIXEL_STRIDE-th pixel or sparser (a stride coprime to the 32-pixel blocks of the ray order)
@@ -34,6 +32,7 @@ FLOP_COUNT_SAMPLES = 48e6
 # passes the random tape always holds, so that qdirs and the draws of the timed passes do not
 # depend on --steps / --warmup (the timed passes come first, warm-up passes after them)
 TAPE_SAMPLES_PER_PIXEL = 4096
+ROOFLINE_LAUNCHES = 10                 # lone launches timed for roofline.kernel_ms_avg
 
 
 def parse_args():
@@ -79,6 +78,9 @@ def parse_args():
     ap.add_argument('--in-flight', default='auto',
                     help='pass-split programs (small frames, meshes): this many steps log their addends at the '
                          'same time, on streams and logs of their own; the sums are added in step order (auto: 2)')
+    ap.add_argument('--outline', default=None,
+                    help="long shape tests (ray marchers, mesh traversals) as functions of their own: 0, 1, "
+                         "'marchers' or 'meshes' (default: the renderer's policy)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='target duration of the CPU baseline sample')
@@ -196,7 +198,9 @@ def main():
                  bake_parameters=None if args.bake is None else bool(args.bake),
                  split_passes=None if args.split_passes is None else bool(args.split_passes),
                  overlap_parts=args.streams if args.streams == 'auto' else int(args.streams),
-                 steps_in_flight=args.in_flight if args.in_flight == 'auto' else int(args.in_flight), **shard.renderer_arguments())
+                 steps_in_flight=args.in_flight if args.in_flight == 'auto' else int(args.in_flight),
+                 outline=None if args.outline is None else {'0': False, '1': True}.get(args.outline, args.outline),
+                 **shard.renderer_arguments())
     if args.pass_groups:
         r.min_pass_groups = args.pass_groups
     shard.configure(r)                          # per-pixel random numbers are keyed by the GLOBAL pass index
@@ -253,6 +257,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Roofline leg, outside the timed region: whole-frame launches, one at a time, each between a HIP
+    # event pair of its own on the stream it is launched on; for a pass-split program the time of
+    # clr_render alone (clr_last_split_ms).  This is the duration rocprofv3's kernel trace reports.
+    lone_ms, n_lone = None, 0
+    if rank == 0 and world == 1:
+        r.overlap_parts, r.steps_in_flight = 1, 1
+        r.acc.finish()
+        times = []
+        for k in range(min(args.steps, ROOFLINE_LAUNCHES)):
+            ms = r.render_resident(k * P, P)
+            times.append(r.acc.last_split_ms()[0] if r.split_passes else ms)
+        lone_ms, n_lone = float(np.mean(times)), len(times)
+
     samples = float(width * height) * P * args.steps * (1 if tiles else world)
     result = {
         'metric': 'Msamples/sec (px*spp/s) on %s' % args.scene, 'value': samples / elapsed / 1e6,
@@ -294,36 +311,65 @@ def main():
                 oracle_renderer = Renderer(load_scene('stream'), seed=args.seed, device=False, rng_mode=args.rng)
             base, flops_per_sample, mesh_bytes, counted = cpu_baseline(oracle_renderer, tape, args.cpu_seconds, n_timed)
             result['cpu_baseline'] = base
-        avg_ms = float(np.mean(kernel_ms))
         launch_samples = float(r.n_pixels) * P
-        if mesh_bytes and args.scene == 'scene-mesh':
-            # mesh traversal: HBM roofline on the algorithmic bytes of the flattened layout
-            # (8 B per node record visited, 36 B per triangle test)
-            achieved = mesh_bytes * launch_samples / (avg_ms * 1e-3) / 1e9
+        # counters of this workload's shipped kernel: rocprofv3 PMC passes over this same command
+        # (tools/profile.sh + tools/summarize_profile.py; counters cannot be read from inside the
+        # run), keyed by scene, launch shape and random number mode
+        pmc = {}
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path)).get('%s %dx%d p%d %s' % (args.scene, width, height, P, args.rng)) or {}
+        traffic = pmc.get('bytes_per_launch')
+        lone_s = lone_ms * 1e-3 if lone_ms else None
+        if lone_s is None:
+            roof = {'bound': 'hbm' if args.scene == 'scene-mesh' else 'valu', 'kernel': 'clr_render',
+                    'note': 'the roofline leg runs at N = 1 only'}
+        elif mesh_bytes and args.scene == 'scene-mesh':
+            # mesh traversal (SURVEY 8d names HBM as its roofline): `achieved` is what actually
+            # crosses the HBM interface (FETCH_SIZE + WRITE_SIZE) per second of a lone launch.  The
+            # algorithmic bytes of the flattened layout (8 B per node record visited, 36 B per
+            # triangle test) are mostly served by L2 / Infinity Cache, so their
+            # rate is reported beside it and is not an HBM fraction.
+            achieved = traffic / lone_s / 1e9 if traffic else None
+            algorithmic = mesh_bytes * launch_samples
             roof = {'bound': 'hbm', 'kernel': 'clr_render', 'unit': 'GB/s', 'peak': PEAK_HBM_GBS,
-                    'achieved': achieved, 'frac': achieved / PEAK_HBM_GBS,
-                    'mesh_bytes_per_sample': mesh_bytes, 'flops_per_sample': flops_per_sample,
-                    'counted_over': counted}
+                    'achieved': achieved, 'frac': achieved / PEAK_HBM_GBS if achieved else None,
+                    'achieved_is': 'HBM bytes per launch by the FETCH_SIZE / WRITE_SIZE counters / duration of a lone launch',
+                    'algorithmic': {'bytes_per_sample': mesh_bytes, 'bytes_per_launch': algorithmic,
+                                    'rate_gbs': algorithmic / lone_s / 1e9,
+                                    'served_by_l2_and_infinity_cache': 1.0 - traffic / algorithmic if traffic else None},
+                    'flops_per_sample': flops_per_sample, 'counted_over': counted}
         else:
-            roof = {'bound': 'valu', 'kernel': 'clr_render', 'unit': 'TFLOP/s',
-                    'peak': PEAK_FP32_VECTOR_TFLOPS, 'peak_non_fma_ops': PEAK_FP32_NON_FMA_TOPS}
+            roof = {'bound': 'valu', 'kernel': 'clr_render', 'unit': 'TFLOP/s', 'peak': PEAK_FP32_VECTOR_TFLOPS}
             if flops_per_sample is not None:
-                achieved = flops_per_sample * launch_samples / (avg_ms * 1e-3) / 1e12
+                achieved = flops_per_sample * launch_samples / lone_s / 1e12
+                whole_job = flops_per_sample * samples / elapsed / 1e12
                 roof.update({'achieved': achieved, 'frac': achieved / PEAK_FP32_VECTOR_TFLOPS,
-                             'frac_of_non_fma_ceiling': achieved / PEAK_FP32_NON_FMA_TOPS,
-                             'flops_per_sample': flops_per_sample, 'counted_over': counted})
-        roof['kernel_ms_avg'] = avg_ms
-        roof['traffic'] = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc):
-            # HBM bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE passes over this same command
-            # (tools/profile.sh + tools/summarize_profile.py; counters cannot be read from inside the
-            # run), keyed by scene, launch shape and random number mode
-            key = '%s %dx%d p%d %s' % (args.scene, width, height, P, args.rng)
-            entry = json.load(open(pmc)).get(key)
-            if entry:
-                roof['traffic'] = entry['bytes_per_launch']
-                roof['traffic_source'] = entry['source']
+                             'flops_per_sample': flops_per_sample, 'counted_over': counted,
+                             # the shipped launch pattern (overlapping launch chains), by the wall clock
+                             # of the timed region: work of all steps / elapsed
+                             'whole_job': {'achieved': whole_job, 'frac': whole_job / PEAK_FP32_VECTOR_TFLOPS,
+                                           'ms_per_step': elapsed / args.steps * 1e3,
+                                           'event_ms_per_step': float(np.mean(kernel_ms))}})
+        # `achieved` divides by this: the average device time of clr_render in whole-frame launches
+        # that run one at a time (a HIP event pair around each, on the stream it is launched on),
+        # made after the timed region.  profiles/<tag>_kernel_stats.csv is rocprofv3 --kernel-trace
+        # --stats of this command with --streams 1 --in-flight 1, where every launch is such a launch.
+        roof['kernel_ms_avg'] = lone_ms
+        roof['kernel_ms_of'] = '%d lone whole-frame launches of %d passes after the timed region' % (n_lone, P)
+        roof['traffic'] = traffic
+        if pmc:
+            roof['traffic_source'] = pmc.get('source')
+            issue, lanes = pmc.get('valu_issue_utilisation'), pmc.get('valu_lane_utilisation')
+            if issue and lanes:
+                # what the hardware executed (not the reference algorithm's operation count): share of
+                # the VALU issue slots used x share of the 64 lanes active in them = executed lane
+                # operations / the 78.6 T lane operations per second of the chip
+                roof['executed'] = {'valu_issue_utilisation': issue, 'valu_lane_utilisation': lanes,
+                                    'lane_ops_frac_of_peak': issue * lanes,
+                                    'valu_insts_per_sample': pmc.get('valu_insts_per_sample'),
+                                    'salu_insts_per_sample': pmc.get('salu_insts_per_sample'),
+                                    'counters_avg_ms': pmc.get('avg_ms')}
         result['roofline'] = roof
         print(json.dumps(result))
     if use_dist:

@@ -73,13 +73,15 @@ def main():
     # whatever number of workers there is, also one (development check on a one-GPU box)
     use_dist = world > 1 or bool(os.environ.get('CLRAY_FORCE_DIST'))
     if use_dist:
-        if args.seed is None:
-            raise SystemExit("--gpus needs --seed: every GPU draws the same global sequence of passes")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         args.device = local_rank
+        args.seed = multi_gpu.common_seed(args.seed, dist, torch.device('cuda', local_rank))
+        if args.append and rank == 0 and '--seed' in sys.argv:
+            print("WARNING: --append with the --seed of the earlier run adds the same samples again; "
+                  "leave --seed out (a fresh common seed is drawn) or change it")
     renderer = raytracer_amd.Renderer(scene, args, seed=args.seed, device_index=args.device, rng_mode=args.rng,
                                       light_samples=args.light_samples, overlap_parts='auto', steps_in_flight='auto', **shard.renderer_arguments())
     shard.configure(renderer)

@@ -172,10 +172,22 @@ typedef struct clr_render_args {
      * flight and the additions in call order (call k + D follows call k on the same stream, so
      * its log is free again); results do not change.  No counterpart in the reference. */
     void *reduce_after;
+    /* per-pixel random numbers on a tile made of every N-th band of the frame's rays (several GPUs,
+     * interleaved tile partition; no counterpart in the reference).  ray_band = 0: the tile is the
+     * contiguous range of rays that starts at first_ray.  ray_band > 0: first_ray is the index
+     * INSIDE the tile of pixel 0 of this call, and ray L of the tile is ray
+     * ray_band_base + (L / ray_band) * ray_band_stride + L % ray_band of the frame. */
+    int ray_band, ray_band_stride, ray_band_base;
 } clr_render_args;
 
 int clr_render_passes(clr_program *prog, const clr_render_args *args, void *stream,
                       float *elapsed_ms);
+
+/* Device times of the two kernels of the last TIMED clr_render_passes call of this context on a
+ * pass-split program (elapsed_ms covers both): clr_render, which logs the addends, and
+ * clr_reduce_log, which adds them.  The per-kernel split of the reference's profiling table
+ * (accelerator.py:83-89, 155-166) for the one call that launches two kernels.  Either may be NULL. */
+int clr_last_split_ms(clr_ctx *ctx, float *render_ms, float *reduce_ms);
 
 /* The same call for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.

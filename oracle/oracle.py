@@ -316,11 +316,14 @@ class OracleScene:
         passes, bounces, rows = tape
         full = self.renderer
         pixel_ids = None
+        ray_index = getattr(full, 'ray_index', None)       # a tile: global index of every local ray
+        if ray_index is not None:
+            pixel_ids = np.ascontiguousarray(ray_index, dtype=np.int32)
         if pixels is not None:
             assert not debug
             cam = np.ascontiguousarray(r.host_cam[pixels], np.float32)
-            first_ray = full.ray_range[0] if getattr(full, 'ray_range', None) else 0
-            pixel_ids = np.ascontiguousarray(np.asarray(pixels, dtype=np.int64) + first_ray, dtype=np.int32)
+            pixels = np.asarray(pixels, dtype=np.int64)
+            pixel_ids = np.ascontiguousarray(ray_index[pixels] if ray_index is not None else pixels, dtype=np.int32)
             r = type('Subset', (), dict(host_cam=cam, n_pixels=cam.shape[0], scene=full.scene))()
         rng = None
         if getattr(full, 'rng_mode', 'tape') == 'philox':

@@ -37,7 +37,8 @@ class RenderArgs(ctypes.Structure):
                 ('rng_seed_lo', ctypes.c_uint), ('rng_seed_hi', ctypes.c_uint),
                 ('first_pass', ctypes.c_int), ('first_ray', ctypes.c_int),
                 ('pass_log', ctypes.c_void_p), ('pass_groups', ctypes.c_int),
-                ('pass_stride', ctypes.c_int), ('reduce_after', ctypes.c_void_p)]
+                ('pass_stride', ctypes.c_int), ('reduce_after', ctypes.c_void_p),
+                ('ray_band', ctypes.c_int), ('ray_band_stride', ctypes.c_int), ('ray_band_base', ctypes.c_int)]
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -82,6 +83,7 @@ def load_library():
         'clr_timer_begin': (ci, [vp, vp]),
         'clr_timer_end': (ci, [vp, vp]),
         'clr_timer_elapsed': (ci, [vp, P(ctypes.c_float)]),
+        'clr_last_split_ms': (ci, [vp, P(ctypes.c_float), P(ctypes.c_float)]),
         'clr_program_build': (ci, [vp, cp, ci, P(cp), P(vp)]),
         'clr_program_destroy': (ci, [vp]),
         'clr_program_set_global': (ci, [vp, cp, vp, ctypes.c_size_t]),
@@ -364,6 +366,12 @@ class Accelerator:
     def stream_wait(self, waiting, on):
         """`waiting` (None = default stream) waits for what is queued on `on` so far; the host does not."""
         _check(self.lib.clr_stream_wait(self.ctx, waiting, on))
+
+    def last_split_ms(self):
+        """(clr_render ms, clr_reduce_log ms) of the last timed launch of a pass-split program."""
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        _check(self.lib.clr_last_split_ms(self.ctx, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def timer_begin(self, stream=None):
         """Start of a timed region of launches on `stream` (one HIP event pair around all of them)."""

@@ -559,6 +559,8 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     if (!prog->rng_mode && !a->bounce_tape)
         return fail("clr_render_passes: bounce_tape is required for a tape program");
     if (a->pass_stride < 0) return fail("clr_render_passes: pass_stride must not be negative");
+    if (a->ray_band < 0 || (a->ray_band > 0 && (a->ray_band_stride < a->ray_band || a->ray_band_base < 0)))
+        return fail("clr_render_passes: ray_band must be 0 or positive with ray_band_stride >= ray_band and ray_band_base >= 0");
     if (prog->regen_mode >= 0 && (a->regenerate != 0) != (prog->regen_mode != 0))
         return fail("clr_render_passes: `regenerate` does not match the form of clr_render the program was generated in");
     if (a->debug_dump && a->n_passes != 1)
@@ -604,8 +606,10 @@ int render_passes(clr_program *prog, const clr_render_args *a, void *stream, flo
     void *pass_log = static_log ? static_log : a->pass_log;
     int pass_groups = a->pass_groups;
     int pass_stride = a->pass_stride > 0 ? a->pass_stride : 1;
+    int ray_band = a->ray_band, ray_band_stride = a->ray_band_stride, ray_band_base = a->ray_band_base;
     void *args[] = {&img, &cam, &pt, &bt, &mr, &vd, &id, &n_pixels, &n_passes, &regen, &dbg,
-                    &seed_lo, &seed_hi, &first_pass, &first_ray, &pass_log, &pass_groups, &pass_stride};
+                    &seed_lo, &seed_hi, &first_pass, &first_ray, &pass_log, &pass_groups, &pass_stride,
+                    &ray_band, &ray_band_stride, &ray_band_base};
     const unsigned rb = render_block();
     const unsigned block[3] = {rb, 1, 1};
     if (!prog->split_mode) {

@@ -384,7 +384,7 @@ static __device__ __attribute__((noinline)) bool clr_segment_generic(PathState *
 ### if renderer.rng_mode == 'philox'
             // the light sample feeds the visibility test and the diffuse stage, both of which
             // need a diffuse bounce to be left and are skipped on the last segment
-            const BounceSample B = clr_draw_bounce(rng_seed_lo, rng_seed_hi, (uint)(first_ray + k),
+            const BounceSample B = clr_draw_bounce(rng_seed_lo, rng_seed_hi, global_ray,
                                                    (uint)(first_pass + {{ pass }} * pass_stride), (uint){{ segment }},
                                                    !is_last && s.diffusions_left > 0);
 ### else
@@ -404,7 +404,8 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
            const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
            const int n_pixels, const int n_passes, const int regen, float4 * __restrict__ dbg_argument,
            const uint rng_seed_lo, const uint rng_seed_hi, const int first_pass, const int first_ray,
-           float * __restrict__ pass_log, const int pass_groups, const int pass_stride)
+           float * __restrict__ pass_log, const int pass_groups, const int pass_stride,
+           const int ray_band, const int ray_band_stride, const int ray_band_base)
 {
     float4 * __restrict__ const dbg = {{ 'dbg_argument' if debug else 'nullptr' }};
 ### if renderer.profile_blocks
@@ -445,6 +446,15 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
         clr_lds_material_scalars[i] = clr_material_scalars[i];
     }
     __syncthreads();
+### endif
+### if renderer.rng_mode == 'philox'
+    // the ray's index in the whole frame keys its random numbers.  A tile is a contiguous range of
+    // rays (first_ray = index of its first ray) or, ray_band > 0, every N-th band of ray_band rays:
+    // local ray L = first_ray + k is ray L % ray_band of band L / ray_band of this tile, and the
+    // tile's bands start ray_band_stride rays apart from ray_band_base on (multi_gpu.py)
+    const int local_ray = first_ray + k;
+    const uint global_ray = ray_band > 0
+        ? (uint)(ray_band_base + (local_ray / ray_band) * ray_band_stride + local_ray % ray_band) : (uint)local_ray;
 ### endif
     clr_acc acc;
 ### if renderer.split_passes

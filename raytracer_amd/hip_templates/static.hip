@@ -11,6 +11,8 @@ struct vec4 { float x, y, z, w; };
 
 #define CLR_FN static __device__ __forceinline__
 #define CLR_FN_MEMBER __device__ __forceinline__
+// shape tests kept out of line (Tracer.outlined): one copy for both object sweeps
+#define CLR_OUTLINED static __device__ __attribute__((noinline))
 
 CLR_FN vec3 make_vec3(float x, float y, float z) { vec3 v; v.x = x; v.y = y; v.z = z; return v; }
 CLR_FN vec3 make_vec3(float4 f) { return make_vec3(f.x, f.y, f.z); }

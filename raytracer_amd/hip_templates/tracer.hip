@@ -17,7 +17,7 @@ CLR_FN void {{ obj.normal_function_name }}(
 
 ### macro tracer_function_base(obj)
 {#- distance to the nearest valid intersection of a ray with the shape, tracer coordinates #}
-template<class CLR_G> CLR_FN void {{ obj.tracer_function_name }}(
+template<class CLR_G> {{ 'CLR_OUTLINED' if obj.outlined else 'CLR_FN' }} void {{ obj.tracer_function_name }}(
         const vec3 origin,
         const vec3 ray,
         const float t_limit,   // upper bound for the distance

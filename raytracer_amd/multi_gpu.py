@@ -13,10 +13,16 @@ path shard is that samples are independent and the image is a sum over passes
           (first_pass = g, pass_stride = N).  Only the order of the final additions differs
           from a single-GPU render (per-rank partial sums), so images agree to float32 rounding
           of the sums, not bit for bit.
-  tiles   rank g renders every pass of rays [g * per_rank, (g + 1) * per_rank), a set of 4-pixel
-          wide column blocks of the frame (the reference's ray order, renderer.py:435-456); the
-          tiles are disjoint, so they are gathered, not summed, and the image equals the
-          single-GPU image bit for bit (a pixel's additions all happen on one GPU, in order).
+  tiles   rank g renders every pass of its tile of the frame's rays; the tiles are disjoint, so
+          they are gathered, not summed, and the image equals the single-GPU image bit for bit (a
+          pixel's additions all happen on one GPU, in order).  A tile is every N-th band of
+          `band_blocks` x 256 consecutive rays, starting with band g (interleaved: a ray-marched
+          object in the middle of the frame is shared by all ranks instead of landing on one;
+          tools/tile_balance.py has the measured imbalance of both forms), or with band_blocks = 0
+          the contiguous range [g * per_rank, (g + 1) * per_rank).  In the reference's ray order
+          (renderer.py:435-456) a band of 4 blocks is a strip 4 pixels wide and 256 pixels high.
+          The gather is one all_gather_into_tensor of equally long (padded) tiles followed by one
+          index_select that puts the bands back into ray order.
 
 bench.py and clray.py --gpus use this module; tests/test_distributed.py runs it on gloo.
 """
@@ -27,19 +33,35 @@ import sys
 import numpy as np
 
 TILE_GRANULE = 256          # rays per thread block of the render kernel
+BAND_BLOCKS = 4             # blocks per band of the interleaved tile partition (default)
 
 
 class Shard:
     """What one rank renders, and how the ranks' results are combined."""
 
-    def __init__(self, partition, rank, world, n_pixels):
+    def __init__(self, partition, rank, world, n_pixels, band_blocks=BAND_BLOCKS):
         if partition not in ('passes', 'tiles'):
             raise ValueError("partition must be 'passes' or 'tiles'")
         if not 0 <= rank < world:
             raise ValueError("rank outside the world")
         self.partition, self.rank, self.world, self.n_pixels = partition, rank, world, n_pixels
         self.tiles = partition == 'tiles' and world > 1
-        if self.tiles:
+        self.ray_bands = None
+        self._unshuffle = None
+        if self.tiles and band_blocks:
+            # interleaved: bands g, g + N, ... of `band` rays; fewer blocks per band on small frames
+            # so that every rank gets one
+            band_blocks = max(1, min(int(band_blocks), -(-n_pixels // TILE_GRANULE) // world))
+            self.band = band = band_blocks * TILE_GRANULE
+            n_bands = -(-n_pixels // band)
+            if rank >= n_bands:
+                raise ValueError("tile partition: %d GPUs for %d rays leave rank %d without a block of %d rays"
+                                 % (world, n_pixels, rank, TILE_GRANULE))
+            self.per_rank = -(-n_bands // world) * band      # the longest tile, the gather's chunk
+            self.ray_bands = (rank, world, band)
+            self.ray_range = None
+            self.frame_rows = self.per_rank * world
+        elif self.tiles:
             # whole blocks of TILE_GRANULE rays; the last ranks may get less (or nothing)
             self.per_rank = -(-n_pixels // world // TILE_GRANULE) * TILE_GRANULE
             first = min(rank * self.per_rank, n_pixels)
@@ -57,7 +79,16 @@ class Shard:
 
     def renderer_arguments(self):
         """Keyword arguments for Renderer(...) on this rank."""
+        if self.ray_bands is not None:
+            return {'ray_bands': self.ray_bands}
         return {'ray_range': self.ray_range} if self.tiles else {}
+
+    def gather_index(self):
+        """Interleaved tiles: for every ray of the frame, its row in the gathered tensor (rank-major,
+        per_rank rows per rank)."""
+        ray = np.arange(self.n_pixels, dtype=np.int64)
+        band_no = ray // self.band
+        return (band_no % self.world) * self.per_rank + (band_no // self.world) * self.band + ray % self.band
 
     def configure(self, renderer):
         renderer.pass_stride = self.pass_stride
@@ -86,11 +117,30 @@ class Shard:
         frame: torch tensor (frame_rows x 4 float32) whose my_rows() this rank has rendered."""
         if self.world == 1:
             return frame
-        if self.tiles:
+        if self.ray_bands is not None:
+            import torch
+            gathered = torch.empty_like(frame)
+            dist.all_gather_into_tensor(gathered, self.my_rows(frame).contiguous())
+            if self._unshuffle is None or self._unshuffle.device != frame.device:
+                self._unshuffle = torch.from_numpy(self.gather_index()).to(frame.device)
+            frame[:self.n_pixels] = gathered.index_select(0, self._unshuffle)
+        elif self.tiles:
             dist.all_gather_into_tensor(frame, self.my_rows(frame).clone())
         else:
             dist.all_reduce(frame)
         return frame
+
+
+def common_seed(seed, dist, device=None):
+    """The seed every rank uses: `seed` if given, else one that rank 0 draws and broadcasts (the
+    reference's unseeded global generator, /root/reference/renderer.py:84-85, for a render whose
+    ranks must all draw the same global sequence of passes).  31 bits: numpy's RandomState takes it."""
+    import torch
+    value = torch.zeros(1, dtype=torch.int64, device=device)
+    if dist.get_rank() == 0:
+        value[0] = int(seed) if seed is not None else int.from_bytes(os.urandom(4), 'little') & 0x7fffffff
+    dist.broadcast(value, src=0)
+    return int(value.item())
 
 
 def stripe(tape, rank, world):

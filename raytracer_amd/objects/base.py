@@ -69,6 +69,13 @@ class Tracer(object):
     # full IEEE evaluation also ends without a hit (true is always allowed).
     can_hit_expression = None
 
+    # True for shapes whose ray test is a long loop with many live values (ray marchers, mesh
+    # traversals).  In scenes with many shape classes the renderer then generates the test as a
+    # function of its own instead of inlining it into both object sweeps (`outlined`, set by the
+    # renderer): one copy of the code, and its registers are live only while it runs.
+    outline_candidate = False
+    outlined = False
+
     def __init__(self, position=(0, 0, 0), **affine_kwargs):
         # non-empty => one generated function per instance instead of one per class
         self.unique_tracer_id = ""

@@ -54,6 +54,7 @@ def _printers():
 
 
 class ImplicitSurface(Tracer):
+    outline_candidate = True
 
     def __init__(self, eq, center=(0, 0, 0), scale=1.0, bndR=None,
                  max_itr=1500, precision=0.001, self_intersection=True):
@@ -119,6 +120,7 @@ class QuaternionJuliaSet(ImplicitSurface):
 
 
 class QuaternionJuliaSet2(Tracer):
+    outline_candidate = True
     """Distance-estimator marching (Hart et al. 1989)."""
 
     def __init__(self, c, julia_itr, center=(0, 0, 0), scale=1.0, **kwargs):
@@ -138,6 +140,7 @@ class QuaternionJuliaSet2(Tracer):
 
 
 class DistanceField(Tracer):
+    outline_candidate = True
 
     def __init__(self, tracer_code, normal_code=None, center=(0, 0, 0), bndR=None,
                  max_itr=1000, precision=1e-5, self_intersection=True):

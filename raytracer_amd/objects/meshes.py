@@ -40,6 +40,7 @@ def generate_smooth_normals(vertices, faces):
 
 
 class TriangleMesh(Tracer):
+    outline_candidate = True
 
     def __init__(self, vertices, faces, normals=None, center=(0, 0, 0), scale=1.0,
                  auto_scale=False, auto_flip_normal=False, shading='flat',
@@ -106,6 +107,7 @@ POOLED_FROM_FACES = 30000     # meshes from this size on get the pooled triangle
 
 
 class Octree(Tracer):
+    outline_candidate = True
 
     MAX_DEPTH = 7
 

@@ -74,7 +74,7 @@ class Renderer:
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
                  min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None,
-                 regenerate=None, light_samples=1, overlap_parts=1, steps_in_flight=1):
+                 regenerate=None, light_samples=1, overlap_parts=1, steps_in_flight=1, outline=None, ray_bands=None):
         self.scene = scene
         # Launch chains on slices of the frame: with k > 1 every launch of
         # render_resident goes out as k launches, one per contiguous slice of the ray order, each
@@ -103,6 +103,11 @@ class Renderer:
         # tile partitioning: (first ray, count) in ray order; a contiguous range of ray
         # indices is a set of 4-pixel-wide column blocks of the frame (get_image_order)
         self.ray_range = ray_range
+        # interleaved tile partitioning: (g, N, band) = every N-th band of `band` consecutive rays,
+        # starting with band g (multi_gpu.py; evens out tiles that differ in cost)
+        self.ray_bands = ray_bands
+        if ray_range is not None and ray_bands is not None:
+            raise ValueError("ray_range and ray_bands exclude each other")
         self.shader = scene.shader(scene)
         self.rng = np.random.RandomState(seed)
         # 'tape': the reference's random numbers, drawn on the host in its order and shared by
@@ -120,6 +125,17 @@ class Renderer:
         self.rng_seed = key * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 & (2**64 - 1)
 
         self._group_objects()
+        # Long shape tests (ray marchers, mesh traversals: Tracer.outline_candidate) as functions of
+        # their own instead of inlined into both object sweeps.  outline: False / True (every
+        # candidate) / 'marchers' / 'meshes'; None = the default policy.
+        if outline is None:
+            outline = self.default_outline(scene)
+        self.outline = outline
+        for obj in scene.objects:
+            tracer = obj.tracer
+            is_mesh = tracer.has_data()
+            tracer.outlined = bool(tracer.outline_candidate and (
+                outline is True or (outline == 'marchers' and not is_mesh) or (outline == 'meshes' and is_mesh)))
         # development switch of the mesh traversal (objects/meshes.py): a module global of counters
         self.profile_blocks = os.environ.get('CLR_BLOCK_PROFILE') == '1'     # development, tools/block_costs.py
         self.profile_mesh_phases = any(getattr(obj.tracer, 'profile_phases', False) for obj in scene.objects)
@@ -172,6 +188,10 @@ class Renderer:
             self.build_options += extra.split()
         if device:
             self.connect(device_index)
+
+    @staticmethod
+    def default_outline(scene):
+        return False
 
     @property
     def regenerate(self):
@@ -338,11 +358,19 @@ class Renderer:
         self.img_shape = tuple(scene.image.size[::-1])          # (H, W)
         self.n_pixels = self.img_shape[0] * self.img_shape[1]
         self.image_order = self.full_image_order = self.get_image_order()
+        self.ray_index = None                   # global index of every local ray (None: the whole frame)
         if self.ray_range is not None:
             first, count = self.ray_range
             assert 0 <= first and first + count <= self.n_pixels and count > 0
-            self.image_order = self.image_order[first:first + count]
-            self.n_pixels = count
+            self.ray_index = np.arange(first, first + count)
+        elif self.ray_bands is not None:
+            g, n, band = self.ray_bands
+            assert 0 <= g < n and band > 0 and g * band < self.n_pixels
+            starts = np.arange(g * band, self.n_pixels, n * band)
+            self.ray_index = np.concatenate([np.arange(b, min(b + band, self.n_pixels)) for b in starts])
+        if self.ray_index is not None:
+            self.image_order = self.image_order[self.ray_index]
+            self.n_pixels = len(self.ray_index)
         self.host_cam = Accelerator.host_vec3_array(
             cam[self.image_order[:, 0], self.image_order[:, 1], 0:3])
 
@@ -682,10 +710,14 @@ class Renderer:
 
     def _rng_args(self, first_pass):
         """The per-pixel random number fields of clr_render_args."""
+        bands = {}
+        if self.ray_bands is not None:
+            g, n, band = self.ray_bands
+            bands = dict(ray_band=int(band), ray_band_stride=int(n * band), ray_band_base=int(g * band))
         return dict(per_pixel_rng=int(self.rng_mode == 'philox'),
                     rng_seed_lo=self.rng_seed & 0xffffffff, rng_seed_hi=(self.rng_seed >> 32) & 0xffffffff,
                     first_pass=int(first_pass), first_ray=self.ray_range[0] if self.ray_range else 0,
-                    pass_stride=int(self.pass_stride))
+                    pass_stride=int(self.pass_stride), **bands)
 
     def render_tape(self, tape, debug=False, stream=None, timed=True, first_pass=0, static_log=False):
         """Render the passes described by `tape` and add them to the image accumulator.

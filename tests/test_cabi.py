@@ -32,8 +32,10 @@ def test_python_prototypes_cover_the_header():
 
 def test_struct_layout_matches_header():
     # size word, 7 pointers, 3 ints, padding, pointer, 5 ints of the per-pixel random number mode +
-    # padding, then the pass-split pair: pointer, int, the pass stride, and the stream of the sums
-    assert ctypes.sizeof(accelerator.RenderArgs) == 8 + 7 * 8 + 3 * 4 + 4 + 8 + 5 * 4 + 4 + 8 + 4 + 4 + 8
+    # padding, then the pass-split pair: pointer, int, the pass stride, the stream of the sums, and
+    # the three ints of the band-interleaved tile + padding
+    assert ctypes.sizeof(accelerator.RenderArgs) == 8 + 7 * 8 + 3 * 4 + 4 + 8 + 5 * 4 + 4 + 8 + 4 + 4 + 8 + 3 * 4 + 4
+    assert accelerator.RenderArgs.ray_band.offset == 136 and accelerator.RenderArgs.ray_band_base.offset == 144
     assert accelerator.RenderArgs.reduce_after.offset == 128
     assert accelerator.RenderArgs.struct_size.offset == 0 and accelerator.RenderArgs.img.offset == 8
     assert accelerator.RenderArgs.pass_log.offset == 112 and accelerator.RenderArgs.pass_groups.offset == 120

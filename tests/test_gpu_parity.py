@@ -127,6 +127,35 @@ def test_tile_partition_reassembles_the_frame():
     assert np.array_equal(total, full)
 
 
+@pytest.mark.parametrize('rng_mode', ['tape', 'philox'])
+def test_interleaved_band_tiles_reassemble_the_frame(rng_mode):
+    """SURVEY section 8e, tiles that differ in cost: rank g of N renders every N-th band of the ray
+    order (multi_gpu.Shard, clr_render_args.ray_band...).  Three such tiles - one-lane and pass-split
+    programs, each as two launch chains, so that launches start inside a tile - put back by
+    gather_index() equal the frame a single renderer makes, bit for bit; with per-pixel random
+    numbers this needs every ray to find its index in the whole frame."""
+    from raytracer_amd.multi_gpu import Shard
+    size, world = (320, 240), 3
+    whole = Renderer(load_scene('scene-dev', size), seed=2, rng_mode=rng_mode, split_passes=False)
+    tape = whole.make_tape(0, 5)
+    whole.upload_tape(tape)
+    whole.render_resident(0, 5)
+    want = whole.img.get()
+    frame = None
+    for g in range(world):
+        shard = Shard('tiles', g, world, whole.n_pixels, band_blocks=2)
+        part = Renderer(load_scene('scene-dev', size), seed=2, rng_mode=rng_mode, split_passes=(g == 1),
+                        overlap_parts=2, **shard.renderer_arguments())
+        assert len(part.part_bounds()) == 3 and part.n_pixels in (25600, 26112)
+        part.upload_tape(tape)
+        part.render_resident(0, 2, timed=False)
+        part.render_resident(2, 3, timed=False)
+        if frame is None:
+            frame = np.zeros((shard.frame_rows, 4), dtype=np.float32)
+        shard.my_rows(frame)[:part.n_pixels] = part.img.get()
+    assert np.array_equal(bits(frame[shard.gather_index()]), bits(want))
+
+
 @pytest.mark.parametrize('flat_layout', ['flat', 'flat-lanes'])
 def test_flattened_octree_matches_reference_stream_and_oracle(flat_layout):
     """BASELINE config C4 at reduced size (14 400 triangles): the flattened HBM layout with the

@@ -41,6 +41,15 @@ SETS = {
         'noslp+scalarq5': (BASE + ['-fno-slp-vectorize', '-DCLR_SCALAR_QUOTIENTS'], {'min_waves_per_simd': 5}),
         'noslp+scalarq6': (BASE + ['-fno-slp-vectorize', '-DCLR_SCALAR_QUOTIENTS'], {'min_waves_per_simd': 6}),
     },
+    # round 3: the ceiling of what FMA contraction can give the shipped kernel (every a*b+c the
+    # compiler can find, not a selective mode), at the tuned hint and its neighbours
+    'fma': {
+        'parity6': (BASE + ['-fno-slp-vectorize'], {'min_waves_per_simd': 6}),
+        'parity8': (BASE + ['-fno-slp-vectorize'], {'min_waves_per_simd': 8}),
+        'contract6': (['-O3', '-ffp-contract=fast', '-fno-slp-vectorize'], {'min_waves_per_simd': 6}),
+        'contract7': (['-O3', '-ffp-contract=fast', '-fno-slp-vectorize'], {'min_waves_per_simd': 7}),
+        'contract8': (['-O3', '-ffp-contract=fast', '-fno-slp-vectorize'], {'min_waves_per_simd': 8}),
+    },
     'codegen3': {
         'parity': (BASE + ['-fno-slp-vectorize'], {}),
         'nopostsched': (BASE + ['-fno-slp-vectorize', '-mllvm', '-enable-post-misched=0'], {}),
@@ -63,6 +72,7 @@ def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
         kwargs = {}
         if isinstance(opts, tuple):
             opts, kwargs = opts
+        kwargs.setdefault('split_passes', False)
         if os.environ.get('HINT'):
             kwargs = dict(kwargs, min_waves_per_simd=int(os.environ['HINT']))
         try:

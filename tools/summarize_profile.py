@@ -102,7 +102,22 @@ def main(tag, key, src=None):
     json.dump(summary, open(os.path.join(DST, tag + '_clr_render.json'), 'w'), indent=1)
     path = os.path.join(DST, 'pmc_traffic.json')
     table = json.load(open(path)) if os.path.exists(path) else {}
-    table[key] = {'bytes_per_launch': fetch + write, 'source': 'profiles/%s_clr_render.json' % tag}
+    entry = {'bytes_per_launch': fetch + write, 'source': 'profiles/%s_clr_render.json' % tag,
+             'hbm_read_bytes_per_launch': fetch, 'hbm_write_bytes_per_launch': write, 'avg_ms': summary['avg_ms']}
+    # key = '<scene> <W>x<H> p<passes> <rng>': samples of one launch
+    try:
+        size, passes = key.split()[1], key.split()[2]
+        launch_samples = int(size.split('x')[0]) * int(size.split('x')[1]) * int(passes.lstrip('p'))
+    except (IndexError, ValueError):
+        launch_samples = None
+    for name in ('valu_issue_utilisation', 'valu_lane_utilisation'):
+        if summary.get(name) is not None:
+            entry[name] = summary[name]
+    if launch_samples and 'SQ_INSTS_VALU' in c:
+        # wave-level instructions per sample of the wave's 64 lanes
+        entry['valu_insts_per_sample'] = c['SQ_INSTS_VALU'] / (launch_samples / 64.0)
+        entry['salu_insts_per_sample'] = c['SQ_INSTS_SALU'] / (launch_samples / 64.0)
+    table[key] = entry
     json.dump(table, open(path, 'w'), indent=1)
     print(json.dumps(summary, indent=1))
 
