@@ -59,6 +59,10 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
     const uint which_subobject, const uint inside, const int diffusions_left,
     const vec3 dest, const int light_id,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g);
+template<class CLR_G>
+CLR_FN float clr_light_visibility_along(const vec3 pos, const uint whichobject,
+    const uint which_subobject, const uint inside, const clr_direction &light_dir, const int light_id,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g);
 ### endif
 
 ### if renderer.light_samples > 1 and renderer.rng_mode == 'philox'
@@ -139,9 +143,10 @@ CLR_FN void clr_closest_hit(const vec3 pos, const vec3 ray, float &isec_dist, ui
 }
 
 // normal of the object that was hit (renderer.py:346-351)
+template<class CLR_G>
 CLR_FN vec3 clr_surface_normal(const vec3 pos, const vec3 ray, const uint whichobject,
     const uint which_subobject, const uint inside,
-    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data)
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g)
 {
 ### if renderer.bake_parameters and n_objects <= 24
     // one case per object: its parameters are literals, so e.g. the normal of a wall is a constant,
@@ -151,31 +156,27 @@ CLR_FN vec3 clr_surface_normal(const vec3 pos, const vec3 ray, const uint whicho
     ### for i in range(count)
     if (whichobject == {{ offset+1+i }})
         return {{ tracer.normal_kernel_name }}(pos, ray, which_subobject, inside, vector_data, integer_data,
-            {{ offset+1+i }}, clr_params + {{ renderer.group_param_base[group] + i*renderer.group_param_stride[group] }});
+            {{ offset+1+i }}, clr_params + {{ renderer.group_param_base[group] + i*renderer.group_param_stride[group] }}, clr_g);
     ### endfor
 ### endfor
 ### else
 ### for tracer, count, offset in renderer.object_groups
     {% if not loop.first %}else {% endif %}if (whichobject >= {{ offset+1 }} && whichobject < {{ offset+1+count }})
         return {{ tracer.normal_kernel_name }}(pos, ray, which_subobject, inside, vector_data, integer_data,
-            (int)whichobject, clr_params + {{ renderer.group_param_base[loop.index0] }} + (whichobject - {{ offset+1 }})*{{ renderer.group_param_stride[loop.index0] }});
+            (int)whichobject, clr_params + {{ renderer.group_param_base[loop.index0] }} + (whichobject - {{ offset+1 }})*{{ renderer.group_param_stride[loop.index0] }}, clr_g);
 ### endfor
 ### endif
     return make_vec3(0.0f, 0.0f, 0.0f);
 }
 
 ### if renderer.bidirectional
-// visibility of the light point from the hit point (renderer.py:373-382, tracer.cl:143-221)
+// visibility of the light point from the hit point (renderer.py:373-382, tracer.cl:143-221):
+// the sweep itself, along light_dir = clr_make_direction(light point - pos)
 template<class CLR_G>
-CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint whichobject,
-    const uint which_subobject, const uint inside, const int diffusions_left,
-    const vec3 dest, const int light_id,
+CLR_FN float clr_light_visibility_along(const vec3 pos, const uint whichobject,
+    const uint which_subobject, const uint inside, const clr_direction &light_dir, const int light_id,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g)
 {
-    if (diffusions_left < 1) return 0.0f;
-    const vec3 to_light = dest - pos;
-    if (dot(normal, to_light) < 0.0f) return 0.0f;
-    const clr_direction light_dir = clr_make_direction(to_light, clr_g);
     clr_guard_upper(light_dir, 0.0f, clr_g);
     const float isec_dist = light_dir.len;
     const vec3 ray = light_dir.unit;
@@ -206,6 +207,21 @@ CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint 
 ### endif
 ### endfor
     return shadow_mask;
+}
+
+// the reference's form: every ray of the segment, with the two early exits of tracer.cl:143-221
+template<class CLR_G>
+CLR_FN float clr_light_visibility(const vec3 pos, const vec3 normal, const uint whichobject,
+    const uint which_subobject, const uint inside, const int diffusions_left,
+    const vec3 dest, const int light_id,
+    const float4 * __restrict__ vector_data, const int * __restrict__ integer_data, CLR_G &clr_g)
+{
+    if (diffusions_left < 1) return 0.0f;
+    const vec3 to_light = dest - pos;
+    if (dot(normal, to_light) < 0.0f) return 0.0f;
+    const clr_direction light_dir = clr_make_direction(to_light, clr_g);
+    return clr_light_visibility_along(pos, whichobject, which_subobject, inside, light_dir, light_id,
+                                      vector_data, integer_data, clr_g);
 }
 ### endif
 
@@ -321,7 +337,7 @@ CLR_FN bool clr_segment(PathState &s, const BounceSample &B, const bool is_last,
     s.which_subobject = which_subobject;
     s.pos += isec_dist * s.ray;
     const vec3 normal = clr_surface_normal(s.pos, s.ray, whichobject, which_subobject, s.inside,
-                                           vector_data, integer_data);
+                                           vector_data, integer_data, clr_g);
     float shadow_mask = 0.0f;
 ### if renderer.bidirectional
     // with a debug dump the visibility of the light point is evaluated for every ray, as the
@@ -660,7 +676,7 @@ clr_first_hit(const float4 * __restrict__ cam, const float4 * __restrict__ pass_
     vec3 normal = make_vec3(0.0f, 0.0f, 0.0f);
     if (whichobject != 0)
         normal = clr_surface_normal(s.pos + isec_dist * s.ray, s.ray, whichobject, which_subobject,
-                                    s.inside, vector_data, integer_data);
+                                    s.inside, vector_data, integer_data, clr_g);
     out_ids[2*k] = (int)whichobject;
     out_ids[2*k+1] = (int)which_subobject;
     out_t[k] = isec_dist;

@@ -120,6 +120,21 @@ struct BounceSample {                    // one record of the random tape (SURVE
 ### endif
 };
 
+// length(v) > m as the reference evaluates it (shader.cl:313: correctly rounded square root of the
+// left-to-right dot product), decided on the squares where that is safe.  With m2 = RN(m m) and
+// eps = 2^-24: d2 > m2 (1 + 2^-20) puts sqrt(d2) above m (1 + 2^-22), more than one unit in the last
+// place above m, so the rounded root exceeds m; d2 < m2 (1 - 2^-20) puts it more than one unit
+// below.  In between, and where a product is not a normal number (the comparisons then fail),
+// the root is taken.
+CLR_FN bool clr_farther_than(const vec3 v, const float m) {
+    const float d2 = dot(v, v), m2 = m * m;
+    const bool normal_range = (m2 > 0x1p-100f) & (m2 < 0x1p+100f);
+    const bool farther = normal_range & (d2 > m2 * 1.00000095f);
+    const bool nearer = normal_range & (d2 < m2 * 0.99999905f);
+    if (farther | nearer) return farther;
+    return sqrtf(d2) > m;
+}
+
 // Runs the stage pipeline for one path segment that ended at s.pos (surface s.whichobject,
 // normal n, segment length last_dist).  Adds radiance to `img`.  Returns false if the path
 // is finished (last segment, or culled).
@@ -202,11 +217,20 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
         }
         else p -= cur_prob;
 
+        // A medium that absorbs nothing (air: most segments of most scenes) has exp(-0 * d) = 1:
+        // clr_expf returns exactly 1.0f for +-0 (k = 0, r = 0, the polynomial ends in p * 0 + 1), and
+        // last_dist is a finite distance, so the three ~30-instruction evaluations are skipped.
 ### if shader.rgb
         cur_col = m_absorption;
-        pipeline_color = make_vec3(clr_expf(-cur_col.x*last_dist), clr_expf(-cur_col.y*last_dist), clr_expf(-cur_col.z*last_dist));
+        pipeline_color = COLOR_ONE;
+        if ((cur_col.x != 0.0f) | (cur_col.y != 0.0f) | (cur_col.z != 0.0f))
+            pipeline_color = make_vec3(clr_expf(-cur_col.x*last_dist), clr_expf(-cur_col.y*last_dist), clr_expf(-cur_col.z*last_dist));
 ### else
-        pipeline_color = clr_expf(-m_absorption*last_dist);
+        pipeline_color = COLOR_ONE;
+        {
+            const float absorption = m_absorption;
+            if (absorption != 0.0f) pipeline_color = clr_expf(-absorption*last_dist);
+        }
 ### endif
         if (p < 0.0f) { s.ray = r; s.ray_color = s.ray_color * pipeline_color; }
     }
@@ -310,7 +334,7 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 ### if renderer.bidirectional
             if (B.light_id > 0) {
                 // next-event estimation towards the light point of this segment
-                if (length(s.pos - B.light_center) > B.min_light_sampling_distance) {
+                if (clr_farther_than(s.pos - B.light_center, B.min_light_sampling_distance)) {
                     s.suppress_emission = B.light_id;
 ### if renderer.light_samples > 1
                     // mean over light_samples points of the light: the terms are summed first and
@@ -326,16 +350,31 @@ CLR_FN bool clr_shade(PathState &s, vec3 n, const float last_distance, const flo
 ### endif
                         vec3 shadow_ray = light_point - s.pos;
                         if (dot(shadow_ray, n) > 0 && dot(shadow_ray, light_normal) < 0) {
-                            // diffusions_left was at least 1 before this stage took one
+                            // diffusions_left was at least 1 before this stage took one, and
+                            // dot(n, shadow_ray) > 0 was just tested: the two early exits of the
+                            // reference's visibility kernel do not apply.  The sweep normalises the
+                            // vector to the light point; its length and unit vector are, bit for
+                            // bit, the distance and direction that the estimate below needs
+                            // (same expression, v / sqrt(dot(v, v))), so they are taken from there.
+                            float shadow_mask, shadow_dist;
+                            if (lazy_visibility) {
+                                const clr_direction light_dir = clr_make_direction(shadow_ray, clr_g);
+                                shadow_mask = clr_light_visibility_along(s.pos, s.whichobject, s.which_subobject, s.inside,
+                                                                         light_dir, B.light_id, vector_data, integer_data, clr_g);
+                                shadow_dist = light_dir.len;
+                                shadow_ray = light_dir.unit;
+                            }
+                            else {
 ### if renderer.light_samples > 1
-                            const float shadow_mask = (!lazy_visibility && light_i == 0) ? eager_shadow_mask :
+                                shadow_mask = light_i == 0 ? eager_shadow_mask :
+                                    clr_light_visibility(s.pos, n, s.whichobject, s.which_subobject, s.inside, 1,
+                                                         light_point, B.light_id, vector_data, integer_data, clr_g);
 ### else
-                            const float shadow_mask = !lazy_visibility ? eager_shadow_mask :
+                                shadow_mask = eager_shadow_mask;
 ### endif
-                                clr_light_visibility(s.pos, n, s.whichobject, s.which_subobject, s.inside, 1,
-                                                     light_point, B.light_id, vector_data, integer_data, clr_g);
-                            const float shadow_dist = length(shadow_ray);
-                            shadow_ray = fast_normalize(shadow_ray);
+                                shadow_dist = length(shadow_ray);
+                                shadow_ray = fast_normalize(shadow_ray);
+                            }
                             const float geom = dot(n, shadow_ray) / CLR_PI_F
                                 * dot(-shadow_ray, light_normal) / (shadow_dist*shadow_dist);
 ### if renderer.light_samples > 1

@@ -162,10 +162,10 @@ template<class CLR_G> CLR_FN void {{ obj.shadow_kernel_name }}(
 
 ### macro normal_kernel(obj)
 // world-space normal at `pos` on object `object_id` of this class (tracer.cl:223-284)
-CLR_FN vec3 {{ obj.normal_kernel_name }}(
+template<class CLR_G> CLR_FN vec3 {{ obj.normal_kernel_name }}(
     const vec3 pos, const vec3 ray, const uint subobject, const uint inside,
     const float4 * __restrict__ vector_data, const int * __restrict__ integer_data,
-    const int object_id, const float4 *P)
+    const int object_id, const float4 *P, CLR_G &clr_g)
 {
     const float4 *p_inverse_affine = P + {{ obj.parameter_types()|length }};
     const vec3 local_pos = apply_affine_transform(p_inverse_affine, pos);
@@ -174,7 +174,15 @@ CLR_FN vec3 {{ obj.normal_kernel_name }}(
         local_pos, subobject, &normal
         {{ tracer_params(obj) }}
     );
+    ### if obj.speculative_normal
+    {   // v / |v| through the short sequences where the guard allows (clr_exact.inl): the same bits
+        const clr_direction unit_normal = clr_make_direction(apply_transposed_linear_transform(p_inverse_affine, normal), clr_g);
+        clr_guard_upper(unit_normal, 0.0f, clr_g);
+        normal = unit_normal.unit;
+    }
+    ### else
     normal = normalize(apply_transposed_linear_transform(p_inverse_affine, normal));
+    ### endif
     ### if obj.auto_flip_normal
         if (dot(normal, ray) > 0) normal = -normal;
     ### else

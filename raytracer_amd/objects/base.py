@@ -69,6 +69,11 @@ class Tracer(object):
     # full IEEE evaluation also ends without a hit (true is always allowed).
     can_hit_expression = None
 
+    # True: the step that normalises the world-space normal uses the guard-aware short sequences
+    # (clr_make_direction).  Only for shapes whose normal has no structurally zero component - a
+    # zero component of a direction fails the guard and the path is walked again.
+    speculative_normal = False
+
     # True for shapes whose ray test is a long loop with many live values (ray marchers, mesh
     # traversals).  In scenes with many shape classes the renderer then generates the test as a
     # function of its own instead of inlining it into both object sweeps (`outlined`, set by the

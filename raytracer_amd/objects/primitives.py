@@ -8,6 +8,7 @@ from ..geometry import Affine, rotation_aligning_vectors
 
 class Sphere(Tracer):
     speculation_friendly = True
+    speculative_normal = True
     # most rays of a frame miss a given sphere: they are told apart before the ray is normalised
     # (a square root, a reciprocal, three quotients), with margins that cover the roundings of
     # the full test (static.hip, clr_unit_sphere_may_be_hit)
