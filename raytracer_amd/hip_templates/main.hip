@@ -293,7 +293,9 @@ CLR_FN BounceSample clr_draw_bounce(const uint seed_lo, const uint seed_hi, cons
 // rec[3] = (dof offset, sharp distance), rec[4] = (camera origin, initial path colour scale)
 CLR_FN void clr_start_path(PathState &s, const float4 * __restrict__ rec, const vec3 base_ray) {
     // the five records are fetched together and the depth-of-field branch is a select: as a branch
-    // it splits the loads into three dependent round trips per pass
+    // it splits the loads into three dependent round trips per pass (measured again in round 3 with
+    // the records in scalar registers: the branch is 4 % slower on scene-dev, 1.4 % on
+    // scene-three-objects, profiles/r03_ab_shading.log)
     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
     const vec3 rot_ray = make_vec3(dot(make_vec3(r0), base_ray), dot(make_vec3(r1), base_ray),
                                    dot(make_vec3(r2), base_ray));

@@ -74,8 +74,11 @@ class Renderer:
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
                  min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None,
-                 regenerate=None, light_samples=1, overlap_parts=1, steps_in_flight=1, outline=None, ray_bands=None):
+                 regenerate=None, light_samples=1, overlap_parts=1, steps_in_flight=1, outline=None, ray_bands=None, variants=()):
         self.scene = scene
+        # development: names of code-generation variants under measurement; a template asks with
+        # {% if 'name' in renderer.variants %} (tools/bench_variants.py times them side by side)
+        self.variants = frozenset(variants) | frozenset(filter(None, os.environ.get('CLR_VARIANTS', '').split(',')))
         # Launch chains on slices of the frame: with k > 1 every launch of
         # render_resident goes out as k launches, one per contiguous slice of the ray order, each
         # slice on a stream of its own.  A slice's launches stay in order, those of different

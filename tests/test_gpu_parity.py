@@ -1052,55 +1052,75 @@ def test_plane_distance_test_agrees_with_the_full_test_on_near_ties():
             assert np.array_equal(bits(r.img.get()), bits(oimg)), (ulps, swap)
 
 
-def test_rays_with_signed_zero_components_parallel_to_box_faces():
-    """Rays exactly parallel to the faces of axis-aligned bodies, with the parallel component +0 or
-    -0: the slope of such a face's plane is a signed zero and the reference divides by it
-    (LayerComponent.cl:3-24, HalfSpaceComponent.cl:3-15: +-inf interval ends).  The speculative
-    arithmetic leaves out products with the zero components of a face normal (clr_dot_lit), which
-    alone would give the zero the other sign; it never gets that far, because a direction with a
-    zero component fails the operand guard (its square is tracked, clr_make_direction) and the path
-    is walked again with the generic arithmetic.  First hits and a rendered image equal the
-    oracle's bit for bit."""
-    from oracle import oracle
+def signed_zero_scene():
+    """Axis-aligned bodies around a ray origin in the middle of the room, off their centre planes,
+    and a frame of rays with one component exactly +0 or -0 (tests below and in test_golden-style
+    CPU rehearsal)."""
     from raytracer_amd.objects import Parallelepiped, Cube, Cylinder
     from raytracer_amd.scenes.default_scenes import BoxScene
     s = BoxScene()
     s.image.size = (128, 64)
     s.get_object('light').bidirectional_light = True
-    origin = np.array(s.camera_position, dtype=np.float64)
-    # bodies whose faces / axis are parallel to the coordinate axes, at the height of the camera
-    s.add_object(Parallelepiped((-0.6, 0.0, origin[2] - 0.3), (0.7, 0, 0), (0, 0.5, 0), (0, 0, 0.6)), 'white')
-    s.add_object(Cube((0.9, 0.4, origin[2]), 0.5), 'glass')
-    s.add_object(Cylinder((0.0, 1.2, origin[2] - 0.4), (0, 0, 1), 0.8, 0.25), 'mirror')
-    r = Renderer(s, seed=3, split_passes=False)
-    assert r.speculate and r.bake_parameters
+    origin = np.array((0.2, 0.2, 1.9))
+    s.add_object(Cube((1.3, 1.2, 2.0), 0.8), 'glass')
+    s.add_object(Cube((-1.1, -1.3, 2.0), 0.8), 'white')
+    s.add_object(Parallelepiped((-1.6, 1.0, 1.6), (0.8, 0, 0), (0, 0.7, 0), (0, 0, 0.8)), 'white')
+    s.add_object(Parallelepiped((0.9, -1.7, 1.6), (0.8, 0, 0), (0, 0.7, 0), (0, 0, 0.8)), 'mirror')
+    s.add_object(Parallelepiped((-0.1, 1.5, 1.5), (0.7, 0, 0), (0, 0.5, 0), (0, 0, 0.9)), 'white')
+    s.add_object(Parallelepiped((-0.1, -2.0, 1.5), (0.7, 0, 0), (0, 0.5, 0), (0, 0, 0.9)), 'glass')
+    s.add_object(Cylinder((1.6, -0.2, 1.5), (0, 0, 1), 0.9, 0.3), 'mirror')
+    s.add_object(Cylinder((-1.5, 0.1, 1.5), (0, 0, 1), 0.9, 0.3), 'white')
+    bodies = (Parallelepiped, Cube, Cylinder)
     rng = np.random.RandomState(5)
-    cam = np.zeros((r.n_pixels, 4), dtype=np.float32)
-    for k in range(r.n_pixels):
+    n = s.image.size[0] * s.image.size[1]
+    cam = np.zeros((n, 4), dtype=np.float32)
+    for k in range(n):
         d = rng.normal(size=3)
-        d[1] = abs(d[1]) + 0.5                      # towards the bodies
         zero_axis = (0, 2, 2, 2)[k % 4]
-        d /= np.linalg.norm(d)
         d[zero_axis] = 0.0
+        d /= np.linalg.norm(d)
         cam[k, :3] = d
         if k % 2:
             cam[k, zero_axis] = np.float32(-0.0)
+    return s, origin, cam, bodies
+
+
+def fixed_camera_tape(r, n_passes, origin):
+    """A tape whose passes use the camera rays as they are (no jitter, no depth of field) from `origin`."""
+    tape = r.make_tape(0, n_passes)
+    tape[0][:, 0:3, :] = 0.0
+    tape[0][:, 0:3, 0:3] = np.eye(3)
+    tape[0][:, 3, :] = 0.0
+    tape[0][:, 4, 0:3] = origin
+    return tape
+
+
+def test_rays_with_signed_zero_components_parallel_to_box_faces():
+    """Rays exactly parallel to the faces of axis-aligned bodies, with the parallel component +0 or
+    -0: the slope of such a face's plane is a signed zero and the reference divides by it
+    (LayerComponent.cl:3-24, HalfSpaceComponent.cl:3-15: interval ends of +-inf, so that the sign of
+    the zero decides between hit and miss).  The speculative arithmetic leaves out products with
+    the zero components of a face normal (clr_dot_lit), which alone would give the zero another
+    sign; it never gets that far, because a direction with a zero component fails the operand guard
+    (its square is tracked, clr_make_direction) and the path is walked again with the generic
+    arithmetic.  First hits, per-segment state and a rendered image equal the oracle's bit for bit."""
+    from oracle import oracle
+    s, origin, cam, bodies = signed_zero_scene()
+    r = Renderer(s, seed=3, split_passes=False)
+    assert r.speculate and r.bake_parameters
     assert np.signbit(cam[1::2]).any() and (cam[:, :3] == 0).sum() >= r.n_pixels
     r.host_cam = cam
     r.cam.set(cam)
-    tape = r.make_tape(0, 4)
-    tape[0][:, 0:3, :] = 0.0
-    tape[0][:, 0:3, 0:3] = np.eye(3)                # no jitter: the crafted directions as they are
-    tape[0][:, 3, :] = 0.0
-    tape[0][:, 4, 0:3] = origin
+    tape = fixed_camera_tape(r, 4, origin)
     one = tuple(x[:1] if x is not None else None for x in tape)
     osc = oracle.OracleScene(r)
     ids, t, normal = r.first_hit(one)
     oids, ot, onormal = osc.first_hit(one)
     assert np.array_equal(ids, oids)
     assert np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(normal), bits(onormal))
-    bodies = [i + 1 for i, o in enumerate(s.objects) if isinstance(o.tracer, (Parallelepiped, Cube, Cylinder))]
-    assert np.isin(oids[:, 0], bodies).mean() > 0.2
+    body_ids = [i + 1 for i, o in enumerate(s.objects) if isinstance(o.tracer, bodies)]
+    on_body = np.isin(oids[:, 0], body_ids)
+    assert 0.03 < on_body.mean() < 0.9
     _, dump = r.render_tape(one, debug=True)
     oimg, odump, _ = osc.render(one, debug=True)
     assert np.array_equal(bits(dump), bits(odump))

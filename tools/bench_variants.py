@@ -61,8 +61,10 @@ SETS = {
 }
 
 
-def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
+def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=9):
     passes = int(os.environ.get('PASSES', passes))
+    if os.environ.get('SIZE'):
+        size = tuple(int(v) for v in os.environ['SIZE'].split('x'))
     rs = {}
     tape = None
     for name, opts in VARIANTS.items():
@@ -82,6 +84,8 @@ def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
             continue
         if tape is None:
             tape = r.make_tape(0, passes)
+        if os.environ.get('TUNE'):
+            r.tune_occupancy(passes=8)
         r.upload_tape(tape)
         r.render_resident(0, passes)
         rs[name] = r
@@ -107,6 +111,16 @@ def main(scene_name='scene-dev', size=(1920, 1080), passes=32, rounds=5):
                  float(np.max(np.abs(t - t0) / np.abs(t0)))))
 
 if __name__ == '__main__':
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and sys.argv[2].startswith('ab:'):
+        # ab:name1,name2+name3  -> the shipped program against the same with those code-generation
+        # variants switched on (Renderer(variants=...)); every result is checked against the first
+        OPTS = BASE + ['-fno-slp-vectorize']
+        VARIANTS = {'shipped': (OPTS, {})}
+        for name in sys.argv[2][3:].split(','):
+            VARIANTS[name] = (OPTS, {'variants': tuple(name.split('+'))})
+        if os.environ.get('SPLIT'):
+            for k in VARIANTS:
+                VARIANTS[k][1]['split_passes'] = bool(int(os.environ['SPLIT']))
+    elif len(sys.argv) > 2:
         VARIANTS = SETS[sys.argv[2]]
     main(*(sys.argv[1:2] or ['scene-dev']))
