@@ -49,6 +49,8 @@ def parse_args():
                          "'sat' triangle against box, 'reference' the reference's bounding-sphere rule")
     ap.add_argument('--mesh-pooled', type=int, default=None,
                     help='scene-mesh: 1/0 triangle tests pooled over the wave or per lane (default: the Octree class decides)')
+    ap.add_argument('--mesh-ropes', type=int, default=None,
+                    help='scene-mesh: 1/0 next leaf through neighbour links or by the descent from the common ancestor (default: links)')
     ap.add_argument('--mesh-depth', type=int, default=None, help='scene-mesh: octree depth (default: by face count)')
     ap.add_argument('--mesh-leaf', type=int, default=None, help='scene-mesh: faces per leaf before a node splits (default 8)')
     ap.add_argument('--marchers', default=None,
@@ -177,6 +179,8 @@ def main():
                 tree['max_faces_per_leaf'] = args.mesh_leaf
             if args.mesh_pooled is not None:
                 tree['pooled'] = bool(args.mesh_pooled)
+            if args.mesh_ropes is not None and layout == 'flat':
+                tree['ropes'] = bool(args.mesh_ropes)
             scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout,
                                                                        overlap=args.mesh_overlap, **tree)
         elif args.scene == 'scene-marchers' and args.marchers is not None:

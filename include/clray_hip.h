@@ -196,7 +196,10 @@ int clr_last_split_ms(clr_ctx *ctx, float *render_ms, float *reduce_ms);
  * the process ends) instead of args->pass_log, which must be NULL.  The call allocates and frees
  * nothing; it fails when n_passes x (1 + 6 max_bounces) x n_pixels x 4 bytes exceed the array
  * (render fewer passes per call).  Results equal clr_render_passes bit for bit.  Every call on a
- * GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race. */
+ * GPU uses that GPU's one array: a call is refused while the previous call on that GPU, made on
+ * ANOTHER stream, is still running (calls on one stream are ordered by the stream); callers that
+ * share the array between threads serialise their calls.  The array's address is looked up per
+ * device in clr_ctx_create; if that fails there, this entry point reports why. */
 #define CLR_STATIC_LOG_BYTES (128u << 20)
 int clr_render_passes_static_log(clr_program *prog, const clr_render_args *args, void *stream,
                                  float *elapsed_ms);
@@ -214,7 +217,9 @@ int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape,
  * ctxs[i]'s GPU): the per-GPU accumulators of a pass-striped render.  clr_allgather_f32
  * concatenates count_per_rank floats of send[i] into every recv[i] (n x count_per_rank floats):
  * the disjoint tiles of a tile-partitioned render.  streams: one hipStream_t per rank or NULL
- * for the default streams; the calls enqueue and return (clr_sync to wait).  RCCL is loaded on
+ * for the default streams; the calls enqueue and return (clr_sync to wait).  The calling thread's
+ * current HIP device is the same after a call as before it.  An error of one rank's collective
+ * is reported after the group has been closed (the group's own error is then dropped).  RCCL is loaded on
  * the first call (dlopen); hosts with one process per GPU use torch.distributed instead
  * (raytracer_amd/multi_gpu.py). */
 typedef struct clr_comm clr_comm;

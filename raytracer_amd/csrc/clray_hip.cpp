@@ -48,9 +48,15 @@ unsigned render_block() {
 static __device__ __align__(256) unsigned char scratch[CLR_STATIC_LOG_BYTES];
 const int kMaxDevices = 64;
 void *g_scratch_ptr[kMaxDevices];
+// the last call that used a device's log: its stream and an event behind its last kernel, so that a
+// call on ANOTHER stream that would overlap it is refused instead of corrupting the log
+hipEvent_t g_scratch_event[kMaxDevices];
+void *g_scratch_stream[kMaxDevices];
+bool g_scratch_used[kMaxDevices];
 std::mutex g_scratch_mutex;
 
-// with `device` current: looks up that device's copy of the array once
+// with `device` current: looks up that device's copy of the array once (and makes the event: the
+// entry point itself creates nothing)
 int resolve_scratch(int device) {
     if (device < 0 || device >= kMaxDevices) return fail("device index beyond the static log table");
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -58,6 +64,7 @@ int resolve_scratch(int device) {
     void *ptr = nullptr;
     if (int rc = check(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(static log)")) return rc;
     if (!ptr) return fail("hipGetSymbolAddress(static log) returned a null address");
+    if (int rc = check(hipEventCreateWithFlags(&g_scratch_event[device], hipEventDisableTiming), "hipEventCreate(static log)")) return rc;
     g_scratch_ptr[device] = ptr;
     return 0;
 }
@@ -228,7 +235,10 @@ int clr_ctx_create(int device_index, clr_ctx **out) {
         return fail("no HIP device available: libclray_hip needs an AMD GPU (gfx950)");
     if (device_index < 0 || device_index >= count) return fail("device index out of range");
     CLR_TRY(hipSetDevice(device_index));
-    if (int rc = resolve_scratch(device_index)) return rc;
+    // the static log of clr_render_passes_static_log is looked up here, at set-up; a device for
+    // which that fails (no code object of the library for it) can still run everything else, and
+    // the entry point reports the failure when it is called
+    if (resolve_scratch(device_index) != 0) (void)hipGetLastError();
     clr_ctx *ctx = new clr_ctx;
     ctx->device = device_index;
     ctx->compact_work = nullptr;
@@ -659,9 +669,26 @@ int clr_render_passes(clr_program *prog, const clr_render_args *a, void *stream,
 int clr_render_passes_static_log(clr_program *prog, const clr_render_args *a, void *stream, float *elapsed_ms) {
     if (!prog) return fail("null argument");
     const int device = prog->ctx->device;
-    void *log = device >= 0 && device < kMaxDevices ? g_scratch_ptr[device] : nullptr;
-    if (!log) return fail("clr_render_passes_static_log: the static log of this device was not set up");
-    return render_passes(prog, a, stream, elapsed_ms, log);
+    if (device < 0 || device >= kMaxDevices) return fail("clr_render_passes_static_log: device index beyond the static log table");
+    if (int rc = set_device(prog->ctx)) return rc;
+    if (!g_scratch_ptr[device])
+        if (int rc = resolve_scratch(device)) return rc;          // set-up failed at clr_ctx_create: say why
+    // one log per GPU: a call on another stream while the last one is still running would write into
+    // the log that call is reading.  (Calls on one stream are ordered; a caller that orders its
+    // streams itself synchronises before the next call.)
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_used[device] && g_scratch_stream[device] != stream &&
+        hipEventQuery(g_scratch_event[device]) == hipErrorNotReady)
+        return fail("clr_render_passes_static_log: the previous call on this GPU is still running on another "
+                    "stream and owns the static log; wait for it (one log per GPU)");
+    (void)hipGetLastError();
+    const int rc = render_passes(prog, a, stream, elapsed_ms, g_scratch_ptr[device]);
+    if (rc == 0 && a && a->n_passes > 0) {
+        CLR_TRY(hipEventRecord(g_scratch_event[device], (hipStream_t)stream));
+        g_scratch_stream[device] = stream;
+        g_scratch_used[device] = true;
+    }
+    return rc;
 }
 
 int clr_first_hit(clr_program *prog, const void *cam, const void *pass_tape, const void *vector_data,

@@ -78,6 +78,14 @@ int check_nccl(int rc, const char *what) {
     return fail(std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
 }
 
+// the collective calls make every rank's device current in turn; the caller's current device is
+// put back when they return
+struct DeviceRestorer {
+    int device = -1;
+    DeviceRestorer() { if (hipGetDevice(&device) != hipSuccess) device = -1; }
+    ~DeviceRestorer() { if (device >= 0) (void)hipSetDevice(device); }
+};
+
 }  // namespace
 
 struct clr_comm {
@@ -89,6 +97,7 @@ extern "C" {
 
 int clr_comm_create(clr_ctx *const *ctxs, int n, clr_comm **out) {
     if (!ctxs || !out || n < 1) return fail("clr_comm_create: bad arguments");
+    DeviceRestorer keep_device;
     std::vector<int> devices;
     for (int i = 0; i < n; ++i) {
         if (!ctxs[i]) return fail("clr_comm_create: null context");
@@ -134,6 +143,7 @@ int clr_allreduce_sum_f32(clr_comm *comm, void *const *buffers, size_t count, vo
     const int n = (int)comm->comms.size();
     for (int i = 0; i < n; ++i)
         if (!buffers[i]) return fail("clr_allreduce_sum_f32: null buffer");
+    DeviceRestorer keep_device;
     if (int rc = check_nccl(g_rccl.GroupStart(), "ncclGroupStart")) return rc;
     int first_error = 0;
     for (int i = 0; i < n && !first_error; ++i) {
@@ -153,6 +163,7 @@ int clr_allgather_f32(clr_comm *comm, const void *const *send, void *const *recv
     const int n = (int)comm->comms.size();
     for (int i = 0; i < n; ++i)
         if (!send[i] || !recv[i]) return fail("clr_allgather_f32: null buffer");
+    DeviceRestorer keep_device;
     if (int rc = check_nccl(g_rccl.GroupStart(), "ncclGroupStart")) return rc;
     int first_error = 0;
     for (int i = 0; i < n && !first_error; ++i) {

@@ -149,15 +149,19 @@
         const int LEVELS = {{ obj.levels }};
         const int MAX_STEPS = {{ obj.max_steps }};
         #define POOL_WORDS 65                          // 64 words of item bits + one, so that a window may reach past the last item
+### if not obj.ropes
         __shared__ int stack_lds[{{ obj.levels }} * 256];
+### endif
         __shared__ float4 pool_origin[256];            // origin.xyz, exit distance of the current leaf
         __shared__ float4 pool_ray[256];               // ray.xyz, face to skip (int bits; -1 = none)
         __shared__ int2 pool_owner[256];               // q-th lane of the wave that stands in a leaf with triangles:
                                                        // (thread index, first record of the leaf - first item of the lane)
         __shared__ unsigned long long pool_ends[4 * POOL_WORDS];   // per wave: bit w set = item w is the last one of its owner
         __shared__ unsigned long long pool_best[256];  // per lane: min of (t bits << 32 | index in leaf)
+### if not obj.ropes
         int *stack = stack_lds + threadIdx.x;
         #define STACK(level) stack[(level) * 256]
+### endif
         #define POOL_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
         ### if obj.profile_phases
         // development build (CLR_MESH_PROFILE=1, tools/mesh_phases.py): cycles per phase, kept per
@@ -201,7 +205,23 @@
 
         int cx = 0, cy = 0, cz = 0;       // integer cell coordinates at the current depth
         int bx = 0, by = 0, bz = 0;       // their lowest bits (position inside the parent)
+### if obj.ropes
+        // Ropes (no counterpart in the reference, which finds the next leaf by a descent from the
+        // common ancestor, Octree.cl:120-160): per (node, exit face) one record (R | depth << 27, R's
+        // node record), R = the deepest node beyond that face that is a leaf or as deep as the node
+        // (objects/meshes.py, octree_ropes); per node its parent, for the rare hop that the
+        // reference's arithmetic takes another way.
+        const int * __restrict__ node_ropes = octree_data + flat_rope_offset;
+        const int * __restrict__ node_parents = octree_data + flat_parent_offset;
+        int node_at = root_data_offset;   // node whose record is in `ahead`
+        int rope_target = -1;             // >= 0: the previous step hopped; R | depth of R << 27
+        int hop_cell = 0;                 // depth << 27 | x << 18 | y << 9 | z of the cell beyond the exit face, at the depth of the leaf left
+        int left_leaf = 0;                // the leaf left | (child number of S - child number of the ancestor + 8) << 27
+        int hop_face = 0;                 // 2 axis + (towards larger coordinates) of that hop
+        const float rope_margin = {{ obj.rope_margin_literal }};
+### else
         STACK(0) = root_data_offset;
+### endif
         int depth = 0;
         float node_size = root_size;
 
@@ -216,6 +236,128 @@
             int count = 0, first = 0;
             bool last_cell = false;       // the ray leaves the tree (or its range) after this cell
             PHASE_ADD(5, 1); PHASE_ADD(6, __popcll(__ballot(!done)));
+### if obj.ropes
+            if (!done) {
+                vec3 ray_pos = origin + seg_begin * ray, node_origin = make_vec3(0.0f, 0.0f, 0.0f);
+                int head = 0, payload = 0, child_idx;
+                clr_i2u record = ahead;
+                if (rope_target >= 0) {
+                    // The hop of the previous step left (depth, cx, cy, cz, node_size) at S, the
+                    // sibling of an ancestor of the leaf just left, from where the reference
+                    // descends again, one dependent record per level, choosing the child under
+                    // ray_pos.  The leaf's rope names R, the deepest node on the way from S to the
+                    // cell beyond the exit face (hop_cell, at the leaf's depth) that is a leaf or
+                    // as deep as the leaf left.  The choices of that descent are arithmetic on
+                    // registers: they are made here without the records, and if every one of them
+                    // leads towards R (all but rays within a rounding error of a cell edge) the
+                    // traversal continues at R with the record that came with the rope.
+                    const int leaf_depth = hop_cell >> 27, hop_x = (hop_cell >> 18) & 511, hop_y = (hop_cell >> 9) & 511,
+                              hop_z = hop_cell & 511, rope_depth = rope_target >> 27;
+                    // Sure without looking at the levels one by one: the cells whose centres the
+                    // descent compares ray_pos with all contain R, so a ray_pos inside R's cell by
+                    // more than the rounding errors of those comparisons (rope_margin: 16 units in
+                    // the last place of the tree's coordinates, the comparisons err by < 3) goes R's
+                    // way at every level.  On the hop axis ray_pos lies on the wall it came through,
+                    // which is an outer wall of S and at least R's size away from all those centres.
+                    const float size_r = node_size * __int_as_float((127 - (rope_depth - depth)) << 23);
+                    bool same_way;
+                    {
+                        const int up = leaf_depth - rope_depth;
+                        const vec3 rc = ray_pos - (root_origin + make_vec3((float)(hop_x >> up), (float)(hop_y >> up), (float)(hop_z >> up))*size_r);
+                        const int hop_axis = hop_face >> 1;
+                        const float wall = (hop_face & 1) ? 0.0f : size_r, quarter = 0.25f*size_r;
+                        const float lo_m = rope_margin, hi_m = size_r - rope_margin;
+                        same_way = (hop_axis == 0 ? fabsf(rc.x - wall) < quarter : (rc.x > lo_m && rc.x < hi_m))
+                                && (hop_axis == 1 ? fabsf(rc.y - wall) < quarter : (rc.y > lo_m && rc.y < hi_m))
+                                && (hop_axis == 2 ? fabsf(rc.z - wall) < quarter : (rc.z > lo_m && rc.z < hi_m));
+                    }
+                    float size_j = same_way ? size_r : node_size;
+                    // otherwise (a ray_pos within the margin of a wall of R) the comparisons themselves
+                    for (int j = same_way ? rope_depth : depth; j < rope_depth; ++j) {
+                        const int up = leaf_depth - j;
+                        const vec3 cell_origin = root_origin + make_vec3((float)(hop_x >> up), (float)(hop_y >> up), (float)(hop_z >> up))*size_j;
+                        const vec3 rc = ray_pos - cell_origin;
+                        const float half = 0.5f*size_j;
+                        same_way = same_way && (1 - (rc.x < half)) == ((hop_x >> (up - 1)) & 1)
+                                            && (1 - (rc.y < half)) == ((hop_y >> (up - 1)) & 1)
+                                            && (1 - (rc.z < half)) == ((hop_z >> (up - 1)) & 1);
+                        size_j *= 0.5f;
+                    }
+                    if (same_way) {
+                        const int up = leaf_depth - rope_depth;
+                        depth = rope_depth;
+                        cx = hop_x >> up; cy = hop_y >> up; cz = hop_z >> up;
+                        bx = cx & 1; by = cy & 1; bz = cz & 1;
+                        node_size = size_j;
+                        node_at = rope_target & 0x7ffffff;
+                    }
+                    else {
+                        // the reference's own way: S is a sibling of the leaf's ancestor at this depth
+                        int at = left_leaf & 0x7ffffff;
+                        for (int j = depth; j < leaf_depth; ++j) at = node_parents[at];
+                        node_at = at + ((left_leaf >> 27) - 8);
+                        record = *(const clr_i2u *)(octree_data + 2*node_at);
+                    }
+                }
+                while (depth < LEVELS-1) {
+                    head = record.x;                   // >= 0: leaf with that many triangles, -1: inner
+                    payload = record.y;                // first triangle record / first child
+                    node_origin = root_origin + make_vec3((float)cx, (float)cy, (float)cz)*node_size;
+                    if (head >= 0) break;
+                    const vec3 rc = ray_pos - node_origin;
+                    const float half = 0.5f*node_size;
+                    bx = 1 - (rc.x < half); by = 1 - (rc.y < half); bz = 1 - (rc.z < half);
+                    child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
+                    node_at = payload + child_idx;
+                    cx = (cx << 1) | bx; cy = (cy << 1) | by; cz = (cz << 1) | bz;
+                    node_size *= 0.5f;
+                    depth++;
+                    if (depth < LEVELS-1) record = *(const clr_i2u *)(octree_data + 2*node_at);
+                }
+                t_out = slopes * (node_origin - origin + far_walls*node_size);
+                seg_end = fminf(fminf(t_out.x, t_out.y), t_out.z);
+                if (head > 0) { count = head; first = payload; }
+
+                // the hop to the neighbour cell does not depend on the triangle tests of this one
+                int hx = 0, hy = 0, hz = 0, face = 0;
+                if (seg_end == t_out.x) { hx = sx; face = 1 - nx; }          // face = 2 axis + (towards larger coordinates)
+                else if (seg_end == t_out.y) { hy = sy; face = 3 - ny; }
+                else if (seg_end == t_out.z) { hz = sz; face = 5 - nz; }
+                const int leaf_at = node_at;
+                hop_cell = (depth << 27) | ((cx + hx) << 18) | ((cy + hy) << 9) | (cz + hz);
+                hop_face = face;
+                rope_target = -1;
+                while (depth > 0) {
+                    bx += hx; by += hy; bz += hz;
+                    if (bx >= 0 && bx <= 1 && by >= 0 && by <= 1 && bz >= 0 && bz <= 1) break;
+                    depth--;
+                    cx >>= 1; cy >>= 1; cz >>= 1;
+                    bx = cx & 1; by = cy & 1; bz = cz & 1;
+                    node_size *= 2.0f;
+                }
+                if (depth == 0) last_cell = true;        // leaves the root cube
+                else {
+                    const int old_idx = ((cx & 1) ? 4 : 0) + ((cy & 1) ? 2 : 0) + ((cz & 1) ? 1 : 0);
+                    cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
+                    child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
+                    left_leaf = leaf_at | ((child_idx - old_idx + 8) << 27);
+                    seg_begin = seg_end;
+                    if (seg_begin > t_limit) last_cell = true;
+                    else if ((hx | hy | hz) == 0) {
+                        // no exit wall found (a NaN among the distances): like the reference, the
+                        // same cell again
+                        rope_target = leaf_at | (hop_cell & (15 << 27));
+                        ahead.x = head; ahead.y = payload;
+                    }
+                    else {
+                        // one 12-byte record per hop: (R | its depth << 27, R's node record)
+                        const int * __restrict__ rope = node_ropes + 3*(6*leaf_at + face);
+                        rope_target = rope[0];
+                        ahead.x = rope[1]; ahead.y = rope[2];
+                    }
+                }
+            }
+### else
             if (!done) {
                 vec3 ray_pos = origin + seg_begin * ray, node_origin = make_vec3(0.0f, 0.0f, 0.0f);
                 int head = 0, payload = 0, child_idx;
@@ -266,6 +408,7 @@
                     else ahead = *(const clr_i2u *)(octree_data + 2*at);
                 }
             }
+### endif
             pool_origin[tid] = make_float4(origin.x, origin.y, origin.z, seg_end);
             pool_best[tid] = ~0ull;
             PHASE_END(2)
@@ -404,7 +547,9 @@
             for (int slot = 0; slot < 10; ++slot)
                 atomicAdd(&clr_mesh_phases[(blockIdx.x & 63) * 16 + slot], (unsigned long long)phase_sum[slot]);
         ### endif
+### if not obj.ropes
         #undef STACK
+### endif
         #undef POOL_SYNC
         #undef POOL_WORDS
         #undef PHASE_ADD

@@ -112,7 +112,7 @@ class Octree(Tracer):
     MAX_DEPTH = 7
 
     def __init__(self, triangle_mesh, max_depth=3, max_faces_per_leaf=5, builder='python',
-                 layout='stream', max_steps=300, pooled=None, overlap='reference'):
+                 layout='stream', max_steps=300, pooled=None, overlap='reference', ropes=None):
         """builder: 'python' (restatement of the reference's construction) or 'native' (C++
         builder of libclray_hip.so, same tree, any size, max_depth up to 20).
         layout: 'stream' = the reference's integer stream; 'flat' = flattened nodes + per-leaf
@@ -136,6 +136,18 @@ class Octree(Tracer):
         if pooled is None:
             pooled = layout == 'flat' and len(triangle_mesh.faces) >= POOLED_FROM_FACES
         self.pooled = bool(pooled)
+        # pooled traversal only: the next leaf through a table of neighbour links instead of a
+        # descent from the common ancestor (octree_ropes below; same leaves, same hits).  The packed
+        # cell coordinates of the kernel hold 9 bits per axis.
+        # Measured on the 1 M-triangle knot (profiles/r03_mesh_ropes.log): bit-identical and 3 % SLOWER
+        # (6 % without the shortcut that skips the level-by-level check) - the node records of the
+        # descent (3.6 MB) live in L2, the rope table (32 MB) does not, so one fetch from it costs
+        # about what the three to five L2 hits of the descent cost.  Off unless asked for.
+        if ropes is None:
+            ropes = False
+        if ropes and not (self.pooled and max_depth <= ROPES_MAX_DEPTH):
+            raise RuntimeError("ropes need the pooled traversal and max_depth <= %d" % ROPES_MAX_DEPTH)
+        self.ropes = bool(ropes)
         # development: cycle counters per phase of the pooled traversal (tools/mesh_phases.py)
         self.profile_phases = os.environ.get('CLR_MESH_PROFILE') == '1'
         if self.pooled and layout != 'flat':
@@ -150,8 +162,16 @@ class Octree(Tracer):
         if self.max_depth >= self.__class__.MAX_DEPTH and builder == 'python':
             raise RuntimeError("max_depth >= MAX_DEPTH")
         if layout != 'stream' or max_steps != 300 or self.max_depth >= self.__class__.MAX_DEPTH:
-            self.unique_tracer_id = '_%s%s_d%d_s%d' % (layout, '_pooled' if self.pooled else '', self.levels, max_steps)
+            self.unique_tracer_id = '_%s%s%s_d%d_s%d' % (layout, '_pooled' if self.pooled else '',
+                                                         '_ropes' if self.ropes else '', self.levels, max_steps)
         self.build()
+
+    @property
+    def rope_margin_literal(self):
+        """16 units in the last place of the largest coordinate of the root cube, as a HIP literal
+        (the pooled traversal's shortcut for hops through ropes, meshes.hip)."""
+        largest = float(numpy.max(numpy.abs(numpy.asarray(self.root.origin, dtype=numpy.float64))) + self.root.size)
+        return float(numpy.float32(16.0 * numpy.spacing(numpy.float32(largest)))).hex() + 'f'
 
     @property
     def levels(self):
@@ -277,7 +297,14 @@ class Octree(Tracer):
             data['vector'] = numpy.vstack([vectors, packed.reshape(-1, 4)])
             nodes = native['flat_nodes'].ravel()
             self.flat_ids_offset = nodes.size
-            data['integer'] = numpy.concatenate([faces, nodes, face_ids])
+            tables = [faces, nodes, face_ids]
+            self.flat_rope_offset = self.flat_parent_offset = 0
+            if self.ropes:
+                ropes, parents = octree_ropes(native['flat_nodes'])
+                self.flat_rope_offset = nodes.size + face_ids.size
+                self.flat_parent_offset = self.flat_rope_offset + ropes.size
+                tables += [ropes.ravel(), parents]
+            data['integer'] = numpy.concatenate(tables)
             self.root_data_offset = 0
         else:
             self.flat_tri_offset = self.flat_ids_offset = 0
@@ -327,14 +354,96 @@ class Octree(Tracer):
     def parameter_declarations(self):
         decls = ['int n_vertices', 'int n_triangles', 'int root_data_offset',
                  'int face_data_length', 'float3 root_origin', 'float root_size']
-        return decls + ['int flat_tri_offset', 'int flat_ids_offset'] if self.layout == 'flat' else decls
+        if self.layout == 'flat':
+            decls += ['int flat_tri_offset', 'int flat_ids_offset']
+        if self.ropes:
+            decls += ['int flat_rope_offset', 'int flat_parent_offset']
+        return decls
 
     def parameter_values(self):
         if not hasattr(self, 'root_data_offset'):
             self.get_data()
         values = [self.triangle_mesh.n_vertices, self.triangle_mesh.n_faces,
                   self.root_data_offset, self.total_faces * 3, self.root.origin, self.root.size]
-        return values + [self.flat_tri_offset, self.flat_ids_offset] if self.layout == 'flat' else values
+        if self.layout == 'flat':
+            values += [self.flat_tri_offset, self.flat_ids_offset]
+        if self.ropes:
+            values += [self.flat_rope_offset, self.flat_parent_offset]
+        return values
+
+
+ROPES_MAX_DEPTH = 9
+
+
+def octree_cells(flat_nodes):
+    """(depth, x, y, z, parent) of every node of a flattened octree (rows (head, payload): head -1 =
+    inner node with its 8 children from record `payload` on, in the order x*4 + y*2 + z; node 0 =
+    root)."""
+    nodes = numpy.asarray(flat_nodes, dtype=numpy.int64).reshape(-1, 2)
+    n = nodes.shape[0]
+    depth = numpy.zeros(n, numpy.int64)
+    cell = numpy.zeros((n, 3), numpy.int64)
+    parent = numpy.full(n, -1, numpy.int64)
+    frontier = numpy.array([0])
+    while frontier.size:
+        inner = frontier[nodes[frontier, 0] == -1]
+        children = (nodes[inner, 1][:, None] + numpy.arange(8)[None, :])
+        bits = numpy.array([[(k >> 2) & 1, (k >> 1) & 1, k & 1] for k in range(8)])
+        depth[children] = depth[inner][:, None] + 1
+        cell[children] = cell[inner][:, None, :] * 2 + bits[None, :, :]
+        parent[children] = inner[:, None]
+        frontier = children.ravel()
+    return depth, cell, parent
+
+
+def octree_ropes(flat_nodes):
+    """Neighbour links of a flattened octree, for the pooled traversal (hip_templates/shapes/
+    meshes.hip).  ropes[node, face] = (R | depth of R << 27, head of R, payload of R), face =
+    2 * axis + (1 if towards larger coordinates), where R is the deepest node that covers the cell
+    beyond that face of `node` (same depth as `node`) and is not deeper than `node`: the neighbour
+    of equal size if the tree has it, else the larger leaf that contains it; -1 where the face lies
+    on the root cube.  Also returns the parent of every node (-1 for the root).  No counterpart in
+    the reference, whose traversal finds the neighbour by a descent from the common ancestor
+    (cl_templates/objects/Octree.cl:120-160); the kernel checks that this descent would arrive at R."""
+    nodes = numpy.asarray(flat_nodes, dtype=numpy.int64).reshape(-1, 2)
+    n = nodes.shape[0]
+    if n >= 1 << 27:
+        raise RuntimeError("octree_ropes: more than 2^27 nodes")
+    depth, cell, parent = octree_cells(nodes)
+    max_depth = int(depth.max())
+    if max_depth > ROPES_MAX_DEPTH:
+        raise RuntimeError("octree_ropes: tree deeper than %d" % ROPES_MAX_DEPTH)
+    key = (cell[:, 0] << 40) | (cell[:, 1] << 20) | cell[:, 2]
+    levels = []
+    for d in range(max_depth + 1):
+        at = numpy.nonzero(depth == d)[0]
+        order = numpy.argsort(key[at], kind='stable')
+        levels.append((key[at][order], at[order]))
+    ropes = numpy.full((n, 6, 3), -1, numpy.int64)
+    for face in range(6):
+        axis, step = face // 2, 2 * (face % 2) - 1
+        beyond = cell.copy()
+        beyond[:, axis] += step
+        inside = (beyond[:, axis] >= 0) & (beyond[:, axis] < (1 << depth))
+        target = numpy.full(n, -1, numpy.int64)
+        open_ = inside.copy()
+        for d in range(max_depth, -1, -1):          # deepest first
+            sel = numpy.nonzero(open_ & (depth >= d))[0]
+            if not sel.size:
+                continue
+            up = (depth[sel] - d)[:, None]
+            c = beyond[sel] >> up
+            k = (c[:, 0] << 40) | (c[:, 1] << 20) | c[:, 2]
+            keys, ids = levels[d]
+            pos = numpy.minimum(numpy.searchsorted(keys, k), keys.size - 1)
+            found = keys[pos] == k
+            target[sel[found]] = ids[pos[found]]
+            open_[sel[found]] = False
+        assert not open_.any(), "a cell inside the root cube is covered by some node"
+        have = target >= 0
+        ropes[have, face, 0] = target[have] | (depth[target[have]] << 27)
+        ropes[have, face, 1:] = nodes[target[have]]
+    return ropes.astype(numpy.int32), parent.astype(numpy.int32)
 
 
 def face_bounding_spheres(vertices, faces):

@@ -86,7 +86,7 @@ class Renderer:
         # drain.  No pixel changes (a pixel belongs to one slice).  1 = everything on the caller's
         # stream, as the reference's single queue.
         self._overlap_parts = overlap_parts
-        self._part_streams = []
+        self._part_streams = {}          # (step slot, slice) -> stream
         # Pass-split programs only: up to d launches of render_resident log their addends at the
         # same time (d logs, d streams per slice); the sums are still added in launch order on the
         # slice's stream, so no pixel changes.  Small frames are bound by their longest path:
@@ -629,24 +629,32 @@ class Renderer:
         after = None
         chained = stream is None and not static_log
         in_flight = self.steps_in_flight if chained and self.split_passes else 1
-        slot = self._launch_counter % in_flight
-        self._launch_counter += 1
+        if chained:
+            slot = self._launch_counter % in_flight
+            self._launch_counter += 1
+        else:
+            # a launch on a stream of the caller's is not ordered against the slices' streams: it
+            # gets an addend log of its own instead of the one a chained launch may still be using
+            slot = 'caller'
         split = self._split_args(count, static_log=static_log, slot=slot)
         parts = self.part_bounds() if chained else [0, self.n_pixels]
         if len(parts) == 2 and in_flight == 1:
             return launch(0, self.n_pixels, stream, timed)
         # pass-split program with several steps in flight: launch k + 1 logs into another buffer on
         # another stream while launch k is still running; its sums are added after launch k's
-        # (clr_render_args.reduce_after).  Stream [slot][slice].
+        # (clr_render_args.reduce_after).  One stream per (slot, slice).
         n_slices = len(parts) - 1
-        while len(self._part_streams) < in_flight * n_slices:
-            self._part_streams.append(self.acc.new_stream())
+
+        def stream_of(step_slot, p):
+            if (step_slot, p) not in self._part_streams:
+                self._part_streams[(step_slot, p)] = self.acc.new_stream()
+            return self._part_streams[(step_slot, p)]
         if timed:
             self.acc.timer_begin()
         for p in range(n_slices):
             if in_flight > 1:
-                after = self._part_streams[(slot - 1) % in_flight * n_slices + p]
-            launch(parts[p], parts[p + 1], self._part_streams[slot * n_slices + p], False)
+                after = stream_of((slot - 1) % in_flight, p)
+            launch(parts[p], parts[p + 1], stream_of(slot, p), False)
         if timed:
             self.join_parts()
             ms = self.acc.timer_end()
@@ -684,7 +692,7 @@ class Renderer:
     def join_parts(self, stream=None):
         """`stream` (None: the default stream) waits for the launches on the slices' streams.  Work
         on the default stream does so by itself (ordinary HIP streams); this is for other streams."""
-        for part_stream in self._part_streams:
+        for part_stream in self._part_streams.values():
             self.acc.stream_wait(stream, part_stream)
 
     def max_passes_per_launch(self):

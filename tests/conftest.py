@@ -35,7 +35,7 @@ def load_scene(name, size=None, **overrides):
                                     Cylinder=shapes.Cylinder, HalfSpace=shapes.HalfSpace)
         scene = golden_scenes.VARIANTS[name](api)
     elif name.startswith('scene-mesh'):
-        # 'scene-mesh:<n_u>x<n_v>:<layout>:<overlap>', layout 'flat-lanes' = flat, not pooled;
+        # 'scene-mesh:<n_u>x<n_v>:<layout>:<overlap>', layout 'flat-lanes' = flat, not pooled, 'flat-ropes';
         # overlap 'reference' (default here: the reference's tree) or 'sat'
         parts = name.split(':')[1:]
         grid, layout, overlap = parts + ['120x60', 'flat', 'reference'][len(parts):]
@@ -43,6 +43,8 @@ def load_scene(name, size=None, **overrides):
         make = runpy.run_path(os.path.join(SCENE_DIR, 'scene-mesh.py'), run_name='lib')['make_scene']
         if layout == 'flat-lanes':
             scene = make(n_u, n_v, layout='flat', pooled=False, overlap=overlap)
+        elif layout == 'flat-ropes':        # pooled tests, next leaf through neighbour links
+            scene = make(n_u, n_v, layout='flat', pooled=True, ropes=True, overlap=overlap)
         else:
             scene = make(n_u, n_v, layout=layout, overlap=overlap, pooled=True if layout == 'flat' else None)
     else:
