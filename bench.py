@@ -137,7 +137,20 @@ def cpu_baseline(renderer, tape, target_seconds, n_timed, first_pass=0):
     t0 = time.time()
     osc.render(sample, n_threads=threads)
     dt = time.time() - t0
+    # the same port in the reference's execution structure (one sweep over the live
+    # rays per object and step with a barrier behind each, culler, compaction; ray state in arrays)
+    structure = None
+    if renderer.rng_mode == 'tape':
+        n_w = int(max(1, min(n, 0.4 * target_seconds / max(t_one, 1e-3))))
+        sample_w = tuple(x[:n_w] if x is not None else None for x in tape)
+        t0 = time.time()
+        _, sweeps = osc.render_wavefront(sample_w, n_threads=threads)
+        dt_w = time.time() - t0
+        structure = {'value': renderer.n_pixels * n_w / dt_w / 1e6, 'unit': 'Msamples/s',
+                     'sweeps_per_pass': sweeps / n_w, 'culler_group': 1,
+                     'sample': '%d sample passes (%.1f s)' % (n_w, dt_w)}
     return {
+        'reference_structure': structure,
         'value': renderer.n_pixels * n / dt / 1e6, 'unit': 'Msamples/s', 'cores': threads,
         'kind': 'port', 'host_cpus': os.cpu_count(),
         'cpus_allowed': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,

@@ -761,7 +761,7 @@ static inline vec3 to_rgb(const orc_scene *sc, vec3 c, vec3 cmask) {
 }
 
 static int shade(const orc_scene *sc, const material_view *m, path_state *s, vec3 n, float last_distance,
-                 float shadow_mask, const bounce_sample *B, int is_last, vec3 cmask, vec3 *img) {
+                 float shadow_mask, const bounce_sample *B, int is_last, vec3 cmask, vec3 *img, int roulette) {
     const int rgb = sc->rgb;
     float p = B->p;
     vec3 r = s->ray;
@@ -928,8 +928,9 @@ static int shade(const orc_scene *sc, const material_view *m, path_state *s, vec
         s->ray = r; s->ray_color = mul3(s->ray_color, pipeline_color);
     }
 
-    /* Russian roulette on the single ray: shader.cl:371-434 with group size 1 */
-    {
+    /* Russian roulette on the single ray: shader.cl:371-434 with group size 1;
+     * the kernel-per-step driver below runs the culler as a step of its own */
+    if (roulette) {
         const float cur_intensity = color2prob(sc, s->ray_color);
         float survive = cur_intensity, russian_prob = 1.0f;
         if (sc->min_russian_prob != 0.0f) {
@@ -1036,7 +1037,7 @@ static int segment(const orc_scene *sc, const material_view *m, path_state *s, c
     if (sc->bidirectional && !is_last)
         shadow_mask = light_visibility(sc, s->pos, normal, whichobject, which_subobject, s->inside,
                                        s->diffusions_left, B->light_point, B->light_id);
-    const int alive = shade(sc, m, s, normal, isec_dist, shadow_mask, B, is_last, cmask, img);
+    const int alive = shade(sc, m, s, normal, isec_dist, shadow_mask, B, is_last, cmask, img, 1);
     if (dbg) {
         put4(dbg, as_float((int)whichobject), as_float((int)which_subobject), as_float((int)s->inside), as_float(s->diffusions_left));
         put4(dbg + 4, isec_dist, alive ? 1.0f : 0.0f, shadow_mask, as_float(s->suppress_emission));
@@ -1094,6 +1095,152 @@ int orc_render(const orc_scene *sc, const float *cam, const float *pass_tape, co
     (void)total_bytes;
 #endif
     if (flops) *flops = total_flops;
+    return 0;
+}
+
+/* ====================================================================================
+ * The same passes in the reference's EXECUTION STRUCTURE (renderer.py:293-433): ray state in
+ * arrays (RayStateBuffers, renderer.py:466-518), one sweep over the live rays per object for the
+ * closest hit, per object for the normal, per object for the light visibility, one for the
+ * shading pipeline (the reference's five stage launches, fused here: a lower bound on its cost),
+ * the culler over groups of `warp_size` consecutive live rays (shader.cl:371-434: a group lives
+ * or dies together, judged by its brightest ray) and the stable compaction of the survivors
+ * (accelerator.py:196-222).  Every sweep is a parallel loop with a barrier behind it, as every
+ * launch of the reference is followed by event.wait() (accelerator.py:80-81).
+ * With warp_size = 1 the sums equal orc_render's bit for bit; larger groups cull other rays (the
+ * estimator stays unbiased).  Tape mode only.  `launches` receives the number of sweeps.
+ * ==================================================================================== */
+int orc_render_wavefront(const orc_scene *sc, const float *cam, const float *pass_tape, const float *bounce_tape,
+                         const float *material_rows, int n_pixels, int n_passes, float *img, int warp_size,
+                         int n_threads, double *launches) {
+    const int stride = sc->n_objects + 1, row_len = 10 * stride;
+    const int bounce_record = ORC_BOUNCE_RECORD + 2 * ((sc->light_samples > 1 ? sc->light_samples : 1) - 1);
+    double n_launches = 0.0;
+    if (warp_size < 1) warp_size = 1;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    path_state *state = malloc(sizeof(path_state) * (size_t)n_pixels);            /* indexed by ray */
+    uint *last_whichobject = malloc(sizeof(uint) * (size_t)n_pixels), *last_subobject = malloc(sizeof(uint) * (size_t)n_pixels);
+    int *pixel = malloc(sizeof(int) * (size_t)n_pixels), *new_pixel = malloc(sizeof(int) * (size_t)n_pixels);
+    float *isec_dist = malloc(sizeof(float) * (size_t)n_pixels), *shadow_mask = malloc(sizeof(float) * (size_t)n_pixels);   /* by thread */
+    vec3 *normal = malloc(sizeof(vec3) * (size_t)n_pixels), *acc = malloc(sizeof(vec3) * (size_t)n_pixels);
+    if (!state || !last_whichobject || !last_subobject || !pixel || !new_pixel || !isec_dist || !shadow_mask || !normal || !acc)
+        return 1;
+    for (int k = 0; k < n_pixels; ++k) acc[k] = v3p(img + 4 * k);
+    for (int pass = 0; pass < n_passes; ++pass) {
+        const float *prec = pass_tape + (size_t)pass * ORC_PASS_RECORD * 4;
+        const vec3 cmask = v3p(prec + 20);
+        material_view m = {sc, material_rows ? material_rows + (size_t)pass * row_len : 0, stride};
+        int n = n_pixels;
+        /* subsample_transform_camera + the fills of renderer.py:300-311 */
+        #pragma omp parallel for schedule(static)
+        for (int k = 0; k < n_pixels; ++k) {
+            start_path(sc, &state[k], prec, v3p(cam + 4 * k));
+            if (!sc->rgb) { state[k].ray_color.y = state[k].ray_color.x; state[k].ray_color.z = state[k].ray_color.x; }
+            pixel[k] = k;
+        }
+        n_launches += 6;
+        for (int b = 0; b < sc->max_bounces && n > 0; ++b) {
+            const int is_last = b == sc->max_bounces - 1;
+            const bounce_sample B = load_bounce(bounce_tape + ((size_t)pass * sc->max_bounces + b) * bounce_record * 4);
+            /* isec_dist.fill, buffers swapped (renderer.py:330-336) */
+            #pragma omp parallel for schedule(static)
+            for (int t = 0; t < n; ++t) {
+                const int k = pixel[t];
+                isec_dist[t] = sc->max_ray_length;
+                last_whichobject[k] = state[k].whichobject;
+                last_subobject[k] = state[k].which_subobject;
+                state[k].whichobject = 0;
+            }
+            n_launches += 1;
+            for (int id = 1; id <= sc->n_objects; ++id) {          /* one tracer kernel per object */
+                #pragma omp parallel for schedule(dynamic, 256)
+                for (int t = 0; t < n; ++t) {
+                    path_state *s = &state[pixel[t]];
+                    const int k = pixel[t];
+                    uint which = s->whichobject, sub = s->whichobject ? s->which_subobject : last_subobject[k];
+                    trace_object(sc, id, s->pos, s->ray, &isec_dist[t], &which, &sub, last_whichobject[k],
+                                 last_subobject[k], s->inside);
+                    s->whichobject = which;
+                    if (which) s->which_subobject = sub;
+                }
+                n_launches += 1;
+            }
+            for (int id = 1; id <= sc->n_objects; ++id) {          /* normal kernels */
+                #pragma omp parallel for schedule(static)
+                for (int t = 0; t < n; ++t) {
+                    path_state *s = &state[pixel[t]];
+                    if (s->whichobject != (uint)id) continue;
+                    s->pos = add3(s->pos, lscale3(isec_dist[t], s->ray));
+                    normal[t] = surface_normal(sc, id, s->pos, s->ray, s->which_subobject, s->inside);
+                }
+                n_launches += 1;
+            }
+            /* visibility of the light point: init_shadow_mask + the sweeps (the per-object loop is
+             * inside light_visibility) */
+            #pragma omp parallel for schedule(dynamic, 256)
+            for (int t = 0; t < n; ++t) {
+                const path_state *s = &state[pixel[t]];
+                shadow_mask[t] = 0.0f;
+                if (s->whichobject && sc->bidirectional && !is_last)
+                    shadow_mask[t] = light_visibility(sc, s->pos, normal[t], s->whichobject, s->which_subobject, s->inside,
+                                                      s->diffusions_left, B.light_point, B.light_id);
+            }
+            if (sc->bidirectional && !is_last) n_launches += 1 + sc->n_objects;
+            /* shading pipeline; a ray that hit nothing ends */
+            #pragma omp parallel for schedule(dynamic, 256)
+            for (int t = 0; t < n; ++t) {
+                const int k = pixel[t];
+                path_state *s = &state[k];
+                int alive = 0;
+                if (s->whichobject) alive = shade(sc, &m, s, normal[t], isec_dist[t], shadow_mask[t], &B, is_last, cmask, &acc[k], 0);
+                if (!alive) pixel[t] = -1 - k;                       /* remembered for the culler's group maximum: dead */
+            }
+            n_launches += is_last ? 2 : 5;
+            if (is_last) break;
+            /* culler: groups of warp_size consecutive threads */
+            #pragma omp parallel for schedule(static)
+            for (int g = 0; g < (n + warp_size - 1) / warp_size; ++g) {
+                const int lo = g * warp_size, hi = lo + warp_size < n ? lo + warp_size : n;
+                float max_value = 0.0f;
+                int any = 0;
+                for (int t = lo; t < hi; ++t)
+                    if (pixel[t] >= 0) {
+                        const float v = color2prob(sc, state[pixel[t]].ray_color);
+                        if (!any || v > max_value) max_value = v;
+                        any = 1;
+                    }
+                float russian_prob = 1.0f;
+                int dead = !any;
+                if (any && sc->min_russian_prob != 0.0f) {
+                    if (max_value > 0.0f) {
+                        russian_prob = fminf(fmaxf(max_value, sc->min_russian_prob), 1.0f);
+                        if (B.russian > russian_prob) dead = 1;
+                    }
+                }
+                if (any && max_value == 0.0f) dead = 1;
+                for (int t = lo; t < hi; ++t) {
+                    if (pixel[t] < 0) { pixel[t] = -1; continue; }
+                    if (dead) pixel[t] = -1;
+                    else if (sc->min_russian_prob != 0.0f && russian_prob < 1.0f)
+                        state[pixel[t]].ray_color = div3(state[pixel[t]].ray_color, russian_prob);
+                }
+            }
+            n_launches += 1;
+            /* stable compaction (find_non_negative) */
+            int kept = 0;
+            for (int t = 0; t < n; ++t)
+                if (pixel[t] >= 0) new_pixel[kept++] = pixel[t];
+            n_launches += 3;
+            { int *tmp = pixel; pixel = new_pixel; new_pixel = tmp; }
+            n = kept;
+        }
+    }
+    for (int k = 0; k < n_pixels; ++k) { img[4 * k] = acc[k].x; img[4 * k + 1] = acc[k].y; img[4 * k + 2] = acc[k].z; }
+    free(state); free(last_whichobject); free(last_subobject); free(pixel); free(new_pixel);
+    free(isec_dist); free(shadow_mask); free(normal); free(acc);
+    if (launches) *launches = n_launches;
     return 0;
 }
 

@@ -93,6 +93,14 @@ int orc_render(const orc_scene *scene, const float *cam, const float *pass_tape,
                const float *bounce_tape, const float *material_rows, int n_pixels, int n_passes,
                float *img, float *dbg, int n_threads, double *flops, const orc_rng *rng);
 
+/* The same passes in the reference's execution structure (renderer.py:293-433): ray state in arrays,
+ * one sweep over the live rays per object and per step with a barrier behind each, the culler over
+ * groups of warp_size consecutive live rays (shader.cl:371-434) and a stable compaction per bounce.
+ * warp_size 1: the sums of orc_render bit for bit.  Tape mode only.  launches: number of sweeps. */
+int orc_render_wavefront(const orc_scene *scene, const float *cam, const float *pass_tape,
+                         const float *bounce_tape, const float *material_rows, int n_pixels, int n_passes,
+                         float *img, int warp_size, int n_threads, double *launches);
+
 int orc_first_hit(const orc_scene *scene, const float *cam, const float *pass_tape, int n_pixels,
                   int *out_ids, float *out_t, float *out_normal /* n x 4 */, int n_threads);
 

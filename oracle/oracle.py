@@ -80,6 +80,9 @@ def load(count_flops=False):
         lib.orc_render.restype = ctypes.c_int
         lib.orc_render.argtypes = [ctypes.POINTER(Scene), fp, fp, fp, fp, ctypes.c_int, ctypes.c_int,
                                    fp, fp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(Rng)]
+        lib.orc_render_wavefront.restype = ctypes.c_int
+        lib.orc_render_wavefront.argtypes = [ctypes.POINTER(Scene), fp, fp, fp, fp, ctypes.c_int, ctypes.c_int,
+                                             fp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.orc_first_hit.restype = ctypes.c_int
         lib.orc_first_hit.argtypes = [ctypes.POINTER(Scene), fp, fp, ctypes.c_int,
                                       ctypes.POINTER(ctypes.c_int), fp, fp, ctypes.c_int]
@@ -352,6 +355,25 @@ class OracleScene:
         lib.orc_last_mesh_bytes.restype = ctypes.c_double
         self.last_mesh_bytes = lib.orc_last_mesh_bytes()
         return img, dump, flops.value
+
+    def render_wavefront(self, tape, img=None, warp_size=1, n_threads=0):
+        """The passes of `tape` (broadcast tape only) in the reference's execution structure: one
+        sweep over the live rays per object and step, culler over groups of `warp_size` rays, stable
+        compaction (orc_render_wavefront).  Returns (img, number of sweeps)."""
+        r = self.renderer
+        assert getattr(r, 'rng_mode', 'tape') == 'tape'
+        passes, bounces, rows = tape
+        if img is None:
+            img = np.zeros((r.n_pixels, 4), dtype=np.float32)
+        passes = np.ascontiguousarray(passes, np.float32)
+        bounces = np.ascontiguousarray(bounces, np.float32)
+        rows_p = _fptr(np.ascontiguousarray(rows, np.float32)) if rows is not None else None
+        launches = ctypes.c_double(0)
+        rc = load().orc_render_wavefront(ctypes.byref(self.c_scene), _fptr(r.host_cam), _fptr(passes), _fptr(bounces),
+                                         rows_p, r.n_pixels, passes.shape[0], _fptr(img), int(warp_size), n_threads,
+                                         ctypes.byref(launches))
+        assert rc == 0
+        return img, launches.value
 
     def first_hit(self, tape, n_threads=0, pixels=None):
         """pixels: ray indices to test instead of the whole frame (one row of results per index)."""

@@ -19,8 +19,17 @@ CLR_MATH_FN unsigned clr_mulhi32(unsigned a, unsigned b) {
 CLR_MATH_FN void clr_philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
                                 unsigned k0, unsigned k1, unsigned out[4]) {
     for (int round = 0; round < 10; ++round) {
+#ifdef CLR_PHILOX_SPLIT_MUL     /* measurement only: high and low half as two multiplications */
         const unsigned hi0 = clr_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const unsigned hi1 = clr_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#else
+        /* both halves of a product from one 32 x 32 -> 64 bit multiplication (v_mad_u64_u32 on the
+         * device: the integer multiplier is the slow unit, and this halves its work) */
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * (unsigned long long)c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+#endif
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;

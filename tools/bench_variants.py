@@ -50,6 +50,10 @@ SETS = {
         'contract7': (['-O3', '-ffp-contract=fast', '-fno-slp-vectorize'], {'min_waves_per_simd': 7}),
         'contract8': (['-O3', '-ffp-contract=fast', '-fno-slp-vectorize'], {'min_waves_per_simd': 8}),
     },
+    'philox': {
+        'mad64': (BASE + ['-fno-slp-vectorize'], {'rng_mode': 'philox'}),
+        'split': (BASE + ['-fno-slp-vectorize', '-DCLR_PHILOX_SPLIT_MUL'], {'rng_mode': 'philox'}),
+    },
     'codegen3': {
         'parity': (BASE + ['-fno-slp-vectorize'], {}),
         'nopostsched': (BASE + ['-fno-slp-vectorize', '-mllvm', '-enable-post-misched=0'], {}),
