@@ -80,6 +80,8 @@ def parse_args():
     ap.add_argument('--in-flight', default='auto',
                     help='pass-split programs (small frames, meshes): this many steps log their addends at the '
                          'same time, on streams and logs of their own; the sums are added in step order (auto: 2)')
+    ap.add_argument('--sorted-paths', type=int, default=None,
+                    help='per-pixel random numbers: 1/0 the paths of a block are sorted before every segment (default: the renderer decides)')
     ap.add_argument('--outline', default=None,
                     help="long shape tests (ray marchers, mesh traversals) as functions of their own: 0, 1, "
                          "'marchers' or 'meshes' (default: the renderer's policy)")
@@ -181,6 +183,8 @@ def main():
     from raytracer_amd.renderer import Renderer
     width, height = (int(v) for v in args.size.lower().split('x'))
 
+    mesh_cache = {}
+
     def load_scene(layout='flat'):
         path = os.path.join(ROOT, 'raytracer_amd', 'scenes', args.scene + '.py')
         if args.scene == 'scene-mesh':
@@ -194,7 +198,15 @@ def main():
                 tree['pooled'] = bool(args.mesh_pooled)
             if args.mesh_ropes is not None and layout == 'flat':
                 tree['ropes'] = bool(args.mesh_ropes)
-            scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout,
+            if 'mesh' not in mesh_cache:
+                # BASELINE config 4, "~1M tris via mesh_formats.py" (SURVEY section 8d): the generated mesh
+                # is written as an OFF file and read back through the native reader (csrc/mesh_io.cpp)
+                import tempfile
+                from raytracer_amd.scenes.library import torus_knot_mesh, mesh_through_off_file
+                with tempfile.TemporaryDirectory() as tmp:
+                    v, f, seconds = mesh_through_off_file(*torus_knot_mesh(n_u, n_v), os.path.join(tmp, 'knot.off'))
+                mesh_cache.update(mesh=(v, f), parse_seconds=seconds)
+            scene = runpy.run_path(path, run_name='lib')['make_scene'](n_u, n_v, layout=layout, mesh=mesh_cache['mesh'],
                                                                        overlap=args.mesh_overlap, **tree)
         elif args.scene == 'scene-marchers' and args.marchers is not None:
             scene = runpy.run_path(path, run_name='lib')['make_scene'](only=args.marchers.split(','))
@@ -216,6 +228,7 @@ def main():
                  split_passes=None if args.split_passes is None else bool(args.split_passes),
                  overlap_parts=args.streams if args.streams == 'auto' else int(args.streams),
                  steps_in_flight=args.in_flight if args.in_flight == 'auto' else int(args.in_flight),
+                 sorted_paths=None if args.sorted_paths is None else bool(args.sorted_paths),
                  outline=None if args.outline is None else {'0': False, '1': True}.get(args.outline, args.outline),
                  **shard.renderer_arguments())
     if args.pass_groups:
@@ -298,7 +311,8 @@ def main():
                                'max_bounces %d), %s, build options %s'
                                % (args.scene, width, height, P, 'RGB' if r.shader.rgb else 'spectral', scene.max_bounces,
                                   'broadcast random tape' if args.rng == 'tape' else
-                                  'per-pixel Philox random numbers' + (', path regeneration' if r.regenerate else ''),
+                                  'per-pixel Philox random numbers' + (', path regeneration' if r.regenerate else '')
+                                  + (', paths sorted per block' if r.sorted_paths else ''),
                                   ' '.join(r.build_options)),
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'speculative_exact_arithmetic': bool(r.speculate),
@@ -313,6 +327,9 @@ def main():
                    'parallelism': ('%s x%d, one all-reduce' % ('tile-partitioned' if tiles else 'pass-striped', world))
                                   if world > 1 else 'single GPU'},
     }
+    if mesh_cache:
+        result['config']['mesh_input'] = ('%d faces written as OFF text and parsed by the native reader in %.2f s '
+                                          '(outside the timed region)' % (len(mesh_cache['mesh'][1]), mesh_cache['parse_seconds']))
     result['config']['timed_samples_per_pixel'] = n_timed * (1 if tiles else world)
     result['config']['timed_region'] = ('%d launches back to back, the exchange step, the copy of the image to '
                                         'host memory' % args.steps)

@@ -12,13 +12,16 @@
  * Common subset of C and HIP, plain binary32 arithmetic in a fixed order (compiled without
  * contraction), CLR_MATH_FN supplies the qualifiers; needs clr_math.inl (clr_logf).
  */
+#ifndef CLR_PHILOX_ROUNDS
+#define CLR_PHILOX_ROUNDS 10         /* Philox-4x32-10, the published default; other values: measurement only */
+#endif
 CLR_MATH_FN unsigned clr_mulhi32(unsigned a, unsigned b) {
     return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32);
 }
 
 CLR_MATH_FN void clr_philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
                                 unsigned k0, unsigned k1, unsigned out[4]) {
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < CLR_PHILOX_ROUNDS; ++round) {
 #ifdef CLR_PHILOX_SPLIT_MUL     /* measurement only: high and low half as two multiplications */
         const unsigned hi0 = clr_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const unsigned hi1 = clr_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;

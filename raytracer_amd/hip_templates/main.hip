@@ -411,6 +411,168 @@ static __device__ __attribute__((noinline)) bool clr_segment_generic(PathState *
             float4 *d = dbg ? dbg + ((size_t){{ segment }} * n_pixels + k) * CLR_DBG_STRIDE : nullptr;
             const float *material_row = material_rows + (size_t){{ pass }} * CLR_MATERIAL_ROW;
 {%- endmacro %}
+{#- Sorted form of clr_render (per-pixel random numbers, one lane per pixel): the paths of a block
+    change lanes before every segment so that the lanes of a wave do like work.  No counterpart in
+    the reference, whose compaction (renderer.py:415-431) only closes the gaps that dead rays leave;
+    same results, because a segment is a pure function of (pixel, pass, segment) and a pixel's sums
+    are added in the order of its one live path. -#}
+{%- macro sorted_render_body() %}
+    {
+        // Every path carries its pixel (slot in the block), pass and segment.  Before each segment the
+        // 256 paths of the block are sorted (stable counting sort over 16 keys: ballots inside a wave,
+        // a 64-entry table across the four waves) by what the segment will do: primary rays first -
+        // neighbouring pixels, the same walls and objects - then the other rays by the octant of their
+        // direction, which decides the walls a ray inside a room can reach, then lanes without a
+        // path, so that whole waves fall out at the end of a launch.  The state travels through LDS.
+        static_assert(CLR_MAX_BOUNCES <= 15, "4 bits of segment number");
+        __shared__ float clr_pixel_rays[3 * 256];
+### if renderer.speculate
+        __shared__ float clr_pixel_sums_at_start[3 * 256];
+### endif
+        __shared__ uint clr_path_words[{{ 14 if shader.rgb else 12 }} * 256];
+        __shared__ int clr_sort_table[64];
+        const int tid = threadIdx.x, wave = tid >> 6;
+        const unsigned long long lanes_before = (1ull << (tid & 63)) - 1ull;
+        clr_pixel_rays[tid] = base_ray.x; clr_pixel_rays[256 + tid] = base_ray.y; clr_pixel_rays[512 + tid] = base_ray.z;
+        clr_pixel_sums[tid] = img0.x; clr_pixel_sums[256 + tid] = img0.y; clr_pixel_sums[512 + tid] = img0.z;
+        if (tid < 64) clr_sort_table[tid] = 0;
+        PathState s;
+        s.pos = s.ray = make_vec3(0.0f, 0.0f, 0.0f); s.ray_color = COLOR_ONE;
+        s.whichobject = s.which_subobject = s.inside = 0; s.diffusions_left = s.suppress_emission = 0;
+        int slot = tid, pass = in_image ? 0 : n_passes, segment = 0;
+        bool active = false, generic_path = false;
+        __syncthreads();
+        for (;;) {
+            // a finished path makes way for the next pass of the same pixel
+            if (!active && pass < n_passes) {
+                clr_start_path(s, pass_tape + (size_t)pass * CLR_PASS_STRIDE,
+                               make_vec3(clr_pixel_rays[slot], clr_pixel_rays[256 + slot], clr_pixel_rays[512 + slot]));
+                segment = 0;
+                active = true;
+                generic_path = false;
+### if renderer.speculate
+                clr_pixel_sums_at_start[slot] = clr_pixel_sums[slot];
+                clr_pixel_sums_at_start[256 + slot] = clr_pixel_sums[256 + slot];
+                clr_pixel_sums_at_start[512 + slot] = clr_pixel_sums[512 + slot];
+### endif
+            }
+            // ---- sort: destination = paths with a smaller key + paths with this key in earlier waves
+            // + such paths in earlier lanes of this wave
+            const int key = !active ? 15 : segment == 0 ? 0
+                : 1 + (s.ray.x < 0.0f ? 1 : 0) + (s.ray.y < 0.0f ? 2 : 0) + (s.ray.z < 0.0f ? 4 : 0);
+            unsigned long long same_key = ~0ull;
+            #pragma unroll
+            for (int bit = 0; bit < 4; ++bit) {
+                const unsigned long long plane = __ballot((key >> bit) & 1);
+                same_key &= ((key >> bit) & 1) ? plane : ~plane;
+            }
+            const int rank_in_wave = __popcll(same_key & lanes_before);
+            if (rank_in_wave == 0) clr_sort_table[key * 4 + wave] = __popcll(same_key);
+            __syncthreads();
+            if (tid < 64) {
+                // exclusive prefix sums of the 64 counts (key-major, wave-minor), in place
+                const int count = clr_sort_table[tid];
+                int sum = count;
+                #pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int below = __shfl_up(sum, d);
+                    if (tid >= d) sum += below;
+                }
+                clr_sort_table[tid] = sum - count;
+            }
+            __syncthreads();
+            const int to = clr_sort_table[key * 4 + wave] + rank_in_wave;
+            const bool none_active = clr_sort_table[15 * 4] == 0;      // the lanes without a path start at 0: all of them
+            {
+                uint *w = clr_path_words + to;
+                w[0 * 256] = __float_as_uint(s.pos.x); w[1 * 256] = __float_as_uint(s.pos.y); w[2 * 256] = __float_as_uint(s.pos.z);
+                w[3 * 256] = __float_as_uint(s.ray.x); w[4 * 256] = __float_as_uint(s.ray.y); w[5 * 256] = __float_as_uint(s.ray.z);
+                w[6 * 256] = s.whichobject | (s.inside << 16);
+                w[7 * 256] = s.which_subobject;
+                w[8 * 256] = (uint)(s.diffusions_left & 0xff) | ((uint)s.suppress_emission << 8);
+                w[9 * 256] = (uint)slot | ((uint)segment << 8) | (generic_path ? 1u << 12 : 0u) | (active ? 1u << 13 : 0u);
+                w[10 * 256] = (uint)pass;
+### if shader.rgb
+                w[11 * 256] = __float_as_uint(s.ray_color.x); w[12 * 256] = __float_as_uint(s.ray_color.y); w[13 * 256] = __float_as_uint(s.ray_color.z);
+### else
+                w[11 * 256] = __float_as_uint(s.ray_color);
+### endif
+            }
+            __syncthreads();
+            if (none_active) break;
+            {
+                const uint *w = clr_path_words + tid;
+                s.pos = make_vec3(__uint_as_float(w[0 * 256]), __uint_as_float(w[1 * 256]), __uint_as_float(w[2 * 256]));
+                s.ray = make_vec3(__uint_as_float(w[3 * 256]), __uint_as_float(w[4 * 256]), __uint_as_float(w[5 * 256]));
+                s.whichobject = w[6 * 256] & 0xffffu; s.inside = w[6 * 256] >> 16;
+                s.which_subobject = w[7 * 256];
+                s.diffusions_left = (int)(w[8 * 256] & 0xffu); s.suppress_emission = (int)w[8 * 256] >> 8;
+                slot = (int)(w[9 * 256] & 0xffu); segment = (int)((w[9 * 256] >> 8) & 0xfu);
+                generic_path = (w[9 * 256] >> 12) & 1u; active = (w[9 * 256] >> 13) & 1u;
+                pass = (int)w[10 * 256];
+### if shader.rgb
+                s.ray_color = make_vec3(__uint_as_float(w[11 * 256]), __uint_as_float(w[12 * 256]), __uint_as_float(w[13 * 256]));
+### else
+                s.ray_color = __uint_as_float(w[11 * 256]);
+### endif
+            }
+            // every wave clears its own column of the table (the entries only it writes) for the next round
+            if ((tid & 63) < 16) clr_sort_table[(tid & 63) * 4 + wave] = 0;
+            if (active) {
+                clr_acc acc;
+                acc.sum = clr_pixel_sums + slot;
+                const int k = blockIdx.x * blockDim.x + slot;          // the pixel of this path
+### if renderer.rng_mode == 'philox'
+                const int local_ray = first_ray + k;
+                const uint global_ray = ray_band > 0
+                    ? (uint)(ray_band_base + (local_ray / ray_band) * ray_band_stride + local_ray % ray_band) : (uint)local_ray;
+### endif
+                const vec3 cmask = make_vec3(pass_tape[(size_t)pass * CLR_PASS_STRIDE + 5]);
+                {{ run_segment('pass', 'segment') }}
+### if renderer.speculate
+                bool alive;
+                bool again = false;
+                if (!generic_path) {
+                    clr_guard_spec spec;
+                    clr_guard_reset(spec);
+                    alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, spec);
+                    if (!clr_guard_ok(spec)) {
+                        // operands left the range of the short sequences: the pixel's sums go back to
+                        // the start of the pass and the path is walked again with the generic arithmetic
+                        acc.set(make_vec3(clr_pixel_sums_at_start[slot], clr_pixel_sums_at_start[256 + slot], clr_pixel_sums_at_start[512 + slot]));
+                        clr_start_path(s, pass_tape + (size_t)pass * CLR_PASS_STRIDE,
+                                       make_vec3(clr_pixel_rays[slot], clr_pixel_rays[256 + slot], clr_pixel_rays[512 + slot]));
+                        segment = 0;
+                        generic_path = true;
+                        again = true;
+                    }
+                }
+                else {
+                    PathState s1 = s;
+                    clr_acc acc1 = acc;
+                    BounceSample B1 = B;
+                    alive = clr_segment_generic(&s1, &B1, is_last, cmask, &acc1, material_row, vector_data, integer_data, d);
+                    s = s1;
+                }
+                if (!again) {
+                    segment++;
+                    if (!alive) { active = false; pass++; }
+                }
+### else
+                const bool alive = clr_segment(s, B, is_last, cmask, acc, material_row, vector_data, integer_data, d, clr_g);
+                segment++;
+                if (!alive) { active = false; pass++; }
+### endif
+            }
+        }
+        if (in_image) img[k] = make_float4(clr_pixel_sums[tid], clr_pixel_sums[256 + tid], clr_pixel_sums[512 + tid], img0.w);
+### if renderer.profile_blocks
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536)
+            atomicMax(&clr_block_cycles[blockIdx.x], (unsigned long long)((long long)__builtin_readcyclecounter() - clr_block_begin));
+### endif
+        return;
+    }
+{%- endmacro %}
 // The kernel exists twice: clr_render, and clr_render_debug for launches with a debug dump.  In
 // clr_render the dump pointer is a null constant, so the stores of the dump and the up-front
 // light visibility sweep that the dump needs (clr_segment) are not part of its code at all.
@@ -474,18 +636,27 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
     const uint global_ray = ray_band > 0
         ? (uint)(ray_band_base + (local_ray / ray_band) * ray_band_stride + local_ray % ray_band) : (uint)local_ray;
 ### endif
+### if renderer.sorted_paths
+    __shared__ float clr_pixel_sums[3 * 256];
+### if not debug
+    {{ sorted_render_body() }}
+### endif
+### endif
     clr_acc acc;
 ### if renderer.split_passes
     acc.stride = (size_t)n_pixels;
     acc.begin_pass(pass_log, 0, kk);
 ### else
-    acc.v = make_vec3(img0.x, img0.y, img0.z);
+### if renderer.sorted_paths
+    acc.sum = clr_pixel_sums + threadIdx.x;
+### endif
+    acc.set(make_vec3(img0.x, img0.y, img0.z));
 ### endif
 
     PathState s;
     vec3 cmask = make_vec3(1.0f, 1.0f, 1.0f);
 ### if renderer.speculate and not renderer.split_passes
-    vec3 acc_at_pass_start = acc.v;
+    vec3 acc_at_pass_start = acc.get();
 ### endif
 
 ### if not renderer.regenerate
@@ -500,7 +671,7 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
     ### endif
     ### if renderer.speculate
         ### if not renderer.split_passes
-        acc_at_pass_start = acc.v;
+        acc_at_pass_start = acc.get();
         ### endif
         // a lane whose operands left the range of the speculative arithmetic abandons the pass
         // and walks it again below with the generic arithmetic
@@ -527,7 +698,7 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
         ### if renderer.split_passes
                 acc.restart_pass();
         ### else
-                acc.v = acc_at_pass_start;
+                acc.set(acc_at_pass_start);
         ### endif
                 clr_start_path(s, rec, base_ray);
                 for (int segment = 0; segment < CLR_MAX_BOUNCES; ++segment) {
@@ -568,7 +739,7 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
     ### endif
     ### if renderer.speculate
         ### if not renderer.split_passes
-            acc_at_pass_start = acc.v;
+            acc_at_pass_start = acc.get();
         ### endif
             generic_path = false;
     ### endif
@@ -589,7 +760,7 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
         ### if renderer.split_passes
                     acc.restart_pass();
         ### else
-                    acc.v = acc_at_pass_start;
+                    acc.set(acc_at_pass_start);
         ### endif
                     clr_start_path(s, pass_tape + (size_t)pass * CLR_PASS_STRIDE, base_ray);
                     segment = 0;
@@ -621,7 +792,7 @@ extern "C" __global__ void __launch_bounds__(256{{ ', %d' % renderer.min_waves_p
     }
 ### endif
 ### if not renderer.split_passes
-    if (in_image) img[k] = make_float4(acc.v.x, acc.v.y, acc.v.z, img0.w);
+    if (in_image) { const vec3 total = acc.get(); img[k] = make_float4(total.x, total.y, total.z, img0.w); }
 ### endif
 ### if renderer.profile_blocks
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536)

@@ -70,9 +70,21 @@ struct clr_acc {
     }
     CLR_FN_MEMBER void restart_pass() { n = 0; first_plus_zero = 0; }
     CLR_FN_MEMBER void end_pass() { *header = __int_as_float(n | (first_plus_zero << 8)); }
+    CLR_FN_MEMBER vec3 get() const { return make_vec3(0.0f, 0.0f, 0.0f); }
+    CLR_FN_MEMBER void set(const vec3) {}
+### elif renderer.sorted_paths
+    // paths change lanes between segments (main.hip, sorted form): the sum of a pixel stays put in
+    // LDS, three planes of 256 floats per block, and whichever lane holds the pixel's path adds to it
+    // (one path per pixel at a time, so the additions keep their order)
+    float *sum;
+    CLR_FN_MEMBER void operator+=(const vec3 a) { sum[0] += a.x; sum[256] += a.y; sum[512] += a.z; }
+    CLR_FN_MEMBER vec3 get() const { return make_vec3(sum[0], sum[256], sum[512]); }
+    CLR_FN_MEMBER void set(const vec3 a) { sum[0] = a.x; sum[256] = a.y; sum[512] = a.z; }
 ### else
     vec3 v;
     CLR_FN_MEMBER void operator+=(const vec3 a) { v += a; }
+    CLR_FN_MEMBER vec3 get() const { return v; }
+    CLR_FN_MEMBER void set(const vec3 a) { v = a; }
 ### endif
 };
 

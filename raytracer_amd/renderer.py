@@ -74,7 +74,7 @@ class Renderer:
     def __init__(self, scene, args=None, seed=None, device=True, build_options=None,
                  device_index=0, bake_parameters=None, ray_range=None,
                  min_waves_per_simd=None, speculate=None, rng_mode='tape', split_passes=None,
-                 regenerate=None, light_samples=1, overlap_parts=1, steps_in_flight=1, outline=None, ray_bands=None, variants=()):
+                 regenerate=None, light_samples=1, overlap_parts=1, steps_in_flight=1, outline=None, ray_bands=None, variants=(), sorted_paths=None):
         self.scene = scene
         # development: names of code-generation variants under measurement; a template asks with
         # {% if 'name' in renderer.variants %} (tools/bench_variants.py times them side by side)
@@ -183,6 +183,17 @@ class Renderer:
         # random numbers (lock-step then keeps pass and segment in scalar registers and reads the
         # tape through scalar loads), +26..44 % once every pixel draws its own
         self._regenerate = (self.rng_mode == 'philox') if regenerate is None else bool(regenerate)
+        # Sorted form of the regenerating kernel (main.hip): the paths of a block change lanes before
+        # every segment - primary rays together, the others by the octant of their direction - so
+        # that the lanes of a wave do like work.  For per-pixel random numbers, where the paths of
+        # neighbouring pixels go their own ways (with the broadcast tape they stay a bundle).
+        if sorted_paths is None:
+            sorted_paths = self.default_sorted_paths()
+        self.sorted_paths = bool(sorted_paths)
+        if self.sorted_paths and (self.split_passes or not self._regenerate or len(scene.objects) >= 1 << 16
+                                  or scene.max_bounces > 15):
+            raise ValueError("sorted_paths needs the regenerating one-lane-per-pixel program, < 65536 objects "
+                             "and at most 15 segments per path")
         self.acc = None
         self.program_code = Compiler(self).make_program()
         self.build_options = list(build_options if build_options is not None else PARITY_OPTIONS)
@@ -196,6 +207,9 @@ class Renderer:
     def default_outline(scene):
         return False
 
+    def default_sorted_paths(self):
+        return False
+
     @property
     def regenerate(self):
         return self._regenerate
@@ -205,6 +219,8 @@ class Renderer:
         """The two forms of clr_render are two programs: switching regenerates and rebuilds."""
         if bool(value) == self._regenerate:
             return
+        if not value:
+            self.sorted_paths = False
         self._regenerate = bool(value)
         self.program_code = Compiler(self).make_program()
         if self.acc is not None:

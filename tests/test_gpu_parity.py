@@ -1131,3 +1131,48 @@ def test_rays_with_signed_zero_components_parallel_to_box_faces():
     r.render_tape(tape)
     oimg, _, _ = osc.render(tape)
     assert np.array_equal(bits(r.img.get()), bits(oimg))
+
+
+@pytest.mark.parametrize('name,size', [('scene-dev', (96, 64)), ('scene-three-objects', (96, 64)),
+                                       ('scene-dev-spectral', (64, 48)), ('scene-test', (64, 40)), ('scene-dev', (30, 22))])
+def test_sorted_paths_change_no_pixel(name, size):
+    """Renderer(sorted_paths=True) (main.hip, sorted form: per-pixel random numbers, the paths of a
+    block change lanes before every segment - north_star's ray compaction against divergence, the
+    role of the reference's per-bounce compaction, renderer.py:415-431).  A segment is a pure
+    function of (pixel, pass, segment) and a pixel's sums are added in the order of its one live
+    path, so the image equals the oracle's bit for bit: whole frames (also one that does not fill
+    its last block), several launches, a tile of the frame, launch chains, the speculative
+    arithmetic with most paths restarting."""
+    from oracle import oracle
+    from raytracer_amd.hip_compiler import PARITY_OPTIONS
+    r = Renderer(load_scene(name, size), seed=3, rng_mode='philox', split_passes=False, sorted_paths=True)
+    assert 'clr_path_words' in r.program_code and r.regenerate
+    osc = oracle.OracleScene(r)
+    tape = r.make_tape(0, 9)
+    r.render_tape(tuple(x[:4] if x is not None else None for x in tape))
+    r.render_tape(tuple(x[4:] if x is not None else None for x in tape), first_pass=4)
+    oimg, _, _ = osc.render(tape)
+    img = r.img.get()
+    assert np.isfinite(img).all() and img[:, :3].max() > 0
+    assert np.array_equal(bits(img), bits(oimg))
+    # the debug dump of such a program comes from the unsorted walk
+    one = tuple(x[:1] if x is not None else None for x in tape)
+    _, dump = r.render_tape(one, debug=True)
+    _, odump, _ = osc.render(one, debug=True)
+    assert np.array_equal(bits(dump), bits(odump))
+    if name != 'scene-dev' or size != (96, 64):
+        return
+    # a tile made of bands of the frame, as two launch chains
+    from raytracer_amd.multi_gpu import Shard
+    shard = Shard('tiles', 1, 2, r.n_pixels, band_blocks=2)
+    part = Renderer(load_scene(name, size), seed=3, rng_mode='philox', split_passes=False, sorted_paths=True,
+                    overlap_parts=2, **shard.renderer_arguments())
+    part.n_pixels >= 8192 or part.part_bounds()
+    part.upload_tape(tape)
+    part.render_resident(0, 9, timed=False)
+    assert np.array_equal(bits(part.img.get()), bits(oimg[part.ray_index]))
+    # most paths leave the range of the short sequences and start again
+    tight = Renderer(load_scene(name, size), seed=3, rng_mode='philox', split_passes=False, sorted_paths=True,
+                     speculate=True, build_options=PARITY_OPTIONS + ['-DCLR_GUARD_LO=0x1p-7f'])
+    tight.render_tape(tape)
+    assert np.array_equal(bits(tight.img.get()), bits(oimg))

@@ -54,6 +54,12 @@ SETS = {
         'mad64': (BASE + ['-fno-slp-vectorize'], {'rng_mode': 'philox'}),
         'split': (BASE + ['-fno-slp-vectorize', '-DCLR_PHILOX_SPLIT_MUL'], {'rng_mode': 'philox'}),
     },
+    # what the generator costs: fewer rounds (NOT the published generator: measurement only)
+    'philox-rounds': {
+        'rounds10': (BASE + ['-fno-slp-vectorize'], {'rng_mode': 'philox'}),
+        'rounds7': (BASE + ['-fno-slp-vectorize', '-DCLR_PHILOX_ROUNDS=7'], {'rng_mode': 'philox'}),
+        'rounds1': (BASE + ['-fno-slp-vectorize', '-DCLR_PHILOX_ROUNDS=1'], {'rng_mode': 'philox'}),
+    },
     'codegen3': {
         'parity': (BASE + ['-fno-slp-vectorize'], {}),
         'nopostsched': (BASE + ['-fno-slp-vectorize', '-mllvm', '-enable-post-misched=0'], {}),

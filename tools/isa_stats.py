@@ -81,6 +81,7 @@ def main():
     ap.add_argument('--kernel', default='clr_render')
     ap.add_argument('--fma', type=int, default=None)
     ap.add_argument('--outline', default=None)
+    ap.add_argument('--sorted', type=int, default=None)
     args = ap.parse_args()
     from conftest import load_scene
     from raytracer_amd.renderer import Renderer
@@ -89,6 +90,9 @@ def main():
     kw = {}
     if args.fma is not None:
         kw['fma'] = bool(args.fma)
+    if args.sorted is not None:
+        kw['sorted_paths'] = bool(args.sorted)
+        kw['split_passes'] = False
     if args.outline is not None:
         kw['outline'] = {'0': False, '1': True}.get(args.outline, args.outline)
     r = Renderer(load_scene(args.scene, (w, h)), seed=0, device=False, min_waves_per_simd=args.hint,

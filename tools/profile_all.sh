@@ -11,6 +11,7 @@ run() { # <dir> <bench args...>
 for cfg in "$@"; do
     case $cfg in
         dev) run prof_dev --steps 20 --warmup 3 || exit 1;;
+        spectral) run prof_spectral --scene scene-dev-spectral --steps 10 --warmup 2 || exit 1;;
         three) run prof_three --scene scene-three-objects --steps 10 --warmup 2 || exit 1;;
         philox) run prof_philox --rng philox --steps 10 --warmup 2 || exit 1;;
         marchers) run prof_marchers --scene scene-marchers --size 3840x2160 --passes-per-step 16 --steps 3 --warmup 1 || exit 1;;

@@ -77,9 +77,14 @@ def main(tag, key, src=None):
         shutil.copy(newest(os.path.join(SRC, 'trace_chains', '*', '*_kernel_stats.csv')),
                     os.path.join(DST, tag + '_chains_kernel_stats.csv'))
         crow = [r for r in csv.DictReader(open(max(chains, key=os.path.getmtime))) if r['Kernel_Name'] == 'clr_render']
+        # the launches of the chains are those on slices of the frame: the most frequent grid size
+        # (bench.py's roofline leg adds a few whole-frame launches behind the timed region)
+        grids = collections.Counter(int(r['Grid_Size_X']) for r in crow)
+        chain_grid = max(grids, key=lambda g: (grids[g], -g))
+        crow = [r for r in crow if int(r['Grid_Size_X']) == chain_grid]
         starts = [int(r['Start_Timestamp']) for r in crow]
         ends = [int(r['End_Timestamp']) for r in crow]
-        per_step = max(1, round(summary['grid'] / max(int(r['Grid_Size_X']) for r in crow)))
+        per_step = max(1, round(summary['grid'] / chain_grid))
         steps = len(crow) / per_step
         # the longest gap-free stretch is the timed loop; warm-up launches are waited for one by one
         summary['launch_chains'] = {
