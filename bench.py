@@ -38,8 +38,8 @@ ROOFLINE_LAUNCHES = 10                 # lone launches timed for roofline.kernel
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)     # 0.15 s of launches on the default workload
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--passes-per-step', type=int, default=32)
     ap.add_argument('--scene', default='scene-dev')
     ap.add_argument('--size', default='1920x1080')
