@@ -73,3 +73,25 @@ def test_static_log_entry_point_refuses_what_it_cannot_do():
     with pytest.raises(ClrError) as err:
         plain.render_tape(plain.make_tape(0, 1), static_log=True)
     assert 'pass-split' in str(err.value)
+
+
+def test_static_log_refuses_a_call_that_would_overlap_the_previous_one_on_another_stream():
+    """One log per GPU: while a call is still running, a call on ANOTHER stream is refused instead
+    of writing into the log the first one is reading; after a wait, and on the same stream, calls
+    go through."""
+    r = Renderer(load_scene('scene-test', (320, 240)), seed=2, split_passes=True)
+    floats = 1 + 6 * r.scene.max_bounces
+    n = min(16, STATIC_LOG_BYTES // (4 * floats * r.n_pixels))
+    tape = r.make_tape(0, n)
+    r.upload_tape(tape)
+    other = r.acc.new_stream()
+    r.render_resident(0, n, timed=False, static_log=True)         # about a millisecond of GPU work, not waited for
+    r.render_resident(0, 1, timed=False, static_log=True)         # same stream: ordered, accepted
+    with pytest.raises(ClrError) as err:
+        r.render_resident(0, n, stream=other, timed=False, static_log=True)
+    assert 'another stream' in str(err.value)
+    r.acc.finish()
+    before = r.img.get()
+    r.render_resident(0, 1, stream=other, timed=False, static_log=True)
+    r.acc.finish(other)
+    assert not np.array_equal(bits(r.img.get()), bits(before))
