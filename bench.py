@@ -174,11 +174,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP back end has no CPU fallback")
-    torch.cuda.set_device(local_rank)
     # CLRAY_FORCE_DIST=1 exercises the RCCL code path with a single rank (development check)
     use_dist = world > 1 or bool(os.environ.get('CLRAY_FORCE_DIST'))
     if use_dist:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        from raytracer_amd.multi_gpu import start_process_group
+        dist, local_rank = start_process_group(local_rank)      # (rehearsals may put several workers on GPU 0)
+    else:
+        torch.cuda.set_device(local_rank)
 
     from raytracer_amd.renderer import Renderer
     width, height = (int(v) for v in args.size.lower().split('x'))
@@ -283,7 +285,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [kernel_ms_total() / args.steps]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -74,11 +74,8 @@ def main():
     use_dist = world > 1 or bool(os.environ.get('CLRAY_FORCE_DIST'))
     if use_dist:
         import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        args.device = local_rank
-        args.seed = multi_gpu.common_seed(args.seed, dist, torch.device('cuda', local_rank))
+        dist, args.device = multi_gpu.start_process_group(local_rank)
+        args.seed = multi_gpu.common_seed(args.seed, dist, torch.device('cuda', args.device))
         if args.append and rank == 0 and '--seed' in sys.argv:
             print("WARNING: --append with the --seed of the earlier run adds the same samples again; "
                   "leave --seed out (a fresh common seed is drawn) or change it")

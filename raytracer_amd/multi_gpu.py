@@ -117,6 +117,14 @@ class Shard:
         frame: torch tensor (frame_rows x 4 float32) whose my_rows() this rank has rendered."""
         if self.world == 1:
             return frame
+        if frame.is_cuda and dist.get_backend() != 'nccl':
+            # rehearsal without RCCL (start_process_group): the same exchange through host memory
+            host = frame.cpu()
+            self._unshuffle = None
+            self.combine(host, dist)
+            self._unshuffle = None
+            frame.copy_(host)
+            return frame
         if self.ray_bands is not None:
             import torch
             gathered = torch.empty_like(frame)
@@ -131,11 +139,30 @@ class Shard:
         return frame
 
 
+def start_process_group(local_rank):
+    """torch.distributed for this worker: RCCL ("nccl") with the worker's own GPU.  Rehearsal on a box
+    with ONE GPU (development, tests/test_gpu_cli.py): CLRAY_DIST_BACKEND=gloo lets several workers
+    share GPU 0 (CLRAY_ONE_GPU=1); the exchange step then goes through host memory (Shard.combine).
+    Returns (torch.distributed, device index of this worker)."""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get('CLRAY_DIST_BACKEND', 'nccl')
+    device = 0 if os.environ.get('CLRAY_ONE_GPU') else local_rank
+    torch.cuda.set_device(device)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', device))
+    else:
+        dist.init_process_group(backend)
+    return dist, device
+
+
 def common_seed(seed, dist, device=None):
     """The seed every rank uses: `seed` if given, else one that rank 0 draws and broadcasts (the
     reference's unseeded global generator, /root/reference/renderer.py:84-85, for a render whose
     ranks must all draw the same global sequence of passes).  31 bits: numpy's RandomState takes it."""
     import torch
+    if dist.get_backend() != 'nccl':
+        device = None
     value = torch.zeros(1, dtype=torch.int64, device=device)
     if dist.get_rank() == 0:
         value[0] = int(seed) if seed is not None else int.from_bytes(os.urandom(4), 'little') & 0x7fffffff

@@ -51,3 +51,41 @@ def test_several_gpu_code_path_with_one_worker(tmp_path):
     for partition in ('passes', 'tiles'):
         run_cli(tmp_path, '--gpus', '1', '--partition', partition, env={'CLRAY_FORCE_DIST': '1'}, launcher=launcher)
         assert np.array_equal(np.load(tmp_path / 'out.raw.npy'), want), partition
+
+
+def test_two_workers_rehearsed_on_one_gpu(tmp_path):
+    """The several-GPU product path with TWO workers: no second GPU on the test box, so both share
+    GPU 0 and the exchange step goes through gloo and host memory (multi_gpu.start_process_group,
+    development switches CLRAY_DIST_BACKEND / CLRAY_ONE_GPU); everything else - sharding, global
+    pass numbering, band tiles, accumulators in torch tensors, image assembly - is the code that
+    runs under RCCL.  Tiles: the sums equal the single-GPU run's bit for bit; passes: up to the
+    rounding of the final addition of the two partial sums.  bench.py --gpus 2 prints its line."""
+    import json
+    want = expected_sums()
+    env = {'CLRAY_DIST_BACKEND': 'gloo', 'CLRAY_ONE_GPU': '1'}
+
+    def launcher(port):
+        return ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                '--master-port', str(port)]
+    port = 29900 + os.getpid() % 300
+    for i, (partition, rng) in enumerate((('tiles', 'tape'), ('tiles', 'philox'), ('passes', 'tape'))):
+        run_cli(tmp_path, '--gpus', '2', '--partition', partition, '--rng', rng, env=env, launcher=launcher(port + i))
+        raw = np.load(tmp_path / 'out.raw.npy')
+        if rng == 'philox':
+            r = Renderer(load_scene('scene-dev', (64, 48), samples_per_pixel=12), seed=5, rng_mode='philox')
+            r.render_samples(0, 12)
+            assert np.array_equal(raw, r.get_image()), partition
+        elif partition == 'tiles':
+            assert np.array_equal(raw, want)
+        else:
+            assert np.allclose(raw, want, rtol=1e-5, atol=1e-6) and raw.mean() > 0
+    for partition in ('passes', 'tiles'):
+        cmd = [sys.executable] + launcher(port + 7) + [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+               '--warmup', '1', '--passes-per-step', '4', '--size', '320x240', '--partition', partition,
+               '--occupancy-hint', 'none', '--no-cpu-baseline']
+        out = subprocess.run(cmd, cwd=str(tmp_path), env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=280)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        line = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1])
+        assert line['n_gpus'] == 2 and line['value'] > 0 and line['scaling'] == ('strong' if partition == 'tiles' else 'weak')
+        assert line['image_mean'] > 0
