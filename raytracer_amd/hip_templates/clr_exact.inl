@@ -77,6 +77,13 @@ CLR_FN float clr_quotient_short(float a, float d, float y) {
     return __builtin_fmaf(r, y, q);
 }
 
+// Square root where no guard is at hand (marching loops): the short sequence inside its range,
+// tested on the spot, the generic expansion outside it (and for NaNs).  Same bits either way.
+CLR_FN float clr_sqrt_ranged(float x) {
+    if (x >= 0x1p-94f && x <= 0x1p+60f) return clr_sqrt_short(x);
+    return sqrtf(x);
+}
+
 // ---- square root
 CLR_FN float clr_sqrt(float x, const clr_guard_safe &) { return sqrtf(x); }
 CLR_FN float clr_sqrt(float x, clr_guard_spec &g) {

@@ -9,6 +9,9 @@
  *
  * Written in the common subset of C and HIP; CLR_MATH_FN supplies the qualifiers.
  */
+#ifndef CLR_LOG_QUOTIENT
+#define CLR_LOG_QUOTIENT(a, d) ((a) / (d))
+#endif
 CLR_MATH_FN float clr_bits_to_float(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
 CLR_MATH_FN int clr_float_to_bits(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 
@@ -49,7 +52,10 @@ CLR_MATH_FN float clr_logf(float x) {
     e += (bits >> 23) - 127;
     bits = (bits & 0x007fffff) + 0x3f3504f3;
     const float f = clr_bits_to_float(bits) - 1.0f;
-    const float s = f / (2.0f + f);
+    /* On the device the quotient goes through the short exact sequence (clr_exact.inl): f is 0 or at
+     * least 2^-24 in magnitude (a difference of binary32 numbers next to 1), the divisor lies in
+     * [1.7, 2.42], so the operands are inside its range by construction and +0 / d comes out +0. */
+    const float s = CLR_LOG_QUOTIENT(f, 2.0f + f);
     const float z = s * s;
     float t = 0.153846154f;                                /* 2/13 */
     t = t * z + 0.181818187f;                              /* 2/11 */

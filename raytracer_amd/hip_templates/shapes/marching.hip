@@ -163,9 +163,11 @@
                 qd = 2*quaternion_mult(q, qd);
                 q = quaternion_square(q) + c;
             }
-            const float l = length(q);
+            // (the two lengths: correctly rounded roots, by the short sequence where the sums of
+            //  squares are inside its range - the iteration can leave it)
+            const float l = clr_sqrt_ranged(dot(q, q));
             // `0.5 * l * log(l) / length(qd)` with a double literal: one rounding at the end
-            const float estimate = (float)(0.5 * (double)l * (double)clr_logf(l) / (double)length(qd));
+            const float estimate = (float)(0.5 * (double)l * (double)clr_logf(l) / (double)clr_sqrt_ranged(dot(qd, qd)));
             const float step = fminf(estimate, longest_step);
             if (step < resolution) {
                 *t_hit = travelled + step;
