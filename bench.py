@@ -49,6 +49,8 @@ def parse_args():
                          "'sat' triangle against box, 'reference' the reference's bounding-sphere rule")
     ap.add_argument('--mesh-pooled', type=int, default=None,
                     help='scene-mesh: 1/0 triangle tests pooled over the wave or per lane (default: the Octree class decides)')
+    ap.add_argument('--mesh-two-level', type=int, default=None,
+                    help='scene-mesh: 1 = node records that take the descent down two levels per memory access, 0 = plain records')
     ap.add_argument('--mesh-ropes', type=int, default=None,
                     help='scene-mesh: 1/0 next leaf through neighbour links or by the descent from the common ancestor (default: links)')
     ap.add_argument('--mesh-depth', type=int, default=None, help='scene-mesh: octree depth (default: by face count)')
@@ -200,6 +202,8 @@ def main():
                 tree['pooled'] = bool(args.mesh_pooled)
             if args.mesh_ropes is not None and layout == 'flat':
                 tree['ropes'] = bool(args.mesh_ropes)
+            if args.mesh_two_level is not None and layout == 'flat':
+                tree['two_level'] = bool(args.mesh_two_level)
             if 'mesh' not in mesh_cache:
                 # BASELINE config 4, "~1M tris via mesh_formats.py" (SURVEY section 8d): the generated mesh
                 # is written as an OFF file and read back through the native reader (csrc/mesh_io.cpp)

@@ -167,13 +167,21 @@
         // development build (CLR_MESH_PROFILE=1, tools/mesh_phases.py): cycles per phase, kept per
         // lane during the call and added by one lane per wave to one of 64 copies of the counters
         #define PHASE_CLOCK() ((long long)__builtin_readcyclecounter())
-        long long phase_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        long long phase_sum[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         #define PHASE_ADD(slot, value) phase_sum[slot] += (long long)(value)
         long long phase_mark = PHASE_CLOCK();
         #define PHASE_END(slot) { const long long now = PHASE_CLOCK(); phase_sum[slot] += now - phase_mark; phase_mark = now; }
+        // parts of a phase (slots 10-13), also inside code that only some lanes run: every lane that
+        // runs it keeps the sum, the lane that walks longest ran all of it (largest sum of the wave)
+        long long split_mark = 0;
+        __shared__ unsigned long long phase_split[4 * 4];
+        #define SPLIT_BEGIN() split_mark = PHASE_CLOCK()
+        #define SPLIT_END(slot) { const long long now = PHASE_CLOCK(); phase_sum[slot] += now - split_mark; split_mark = now; }
         ### else
         #define PHASE_ADD(slot, value)
         #define PHASE_END(slot)
+        #define SPLIT_BEGIN()
+        #define SPLIT_END(slot)
         ### endif
 
         const int tid = threadIdx.x, wave_base = tid & ~63;
@@ -359,9 +367,46 @@
             }
 ### else
             if (!done) {
+                SPLIT_BEGIN();
                 vec3 ray_pos = origin + seg_begin * ray, node_origin = make_vec3(0.0f, 0.0f, 0.0f);
                 int head = 0, payload = 0, child_idx;
                 clr_i2u record = ahead;
+### if obj.two_level
+                // Records of objects/meshes.py: octree_two_level.  An inner node's record says which of
+                // its children are inner nodes and where their children lie, so where the child under
+                // ray_pos is one of them the descent goes on to the grandchild (the choice is
+                // arithmetic on registers) and only the grandchild's record is read: the reference's
+                // node sequence, one dependent access per two levels.
+                while (depth < LEVELS-1) {
+                    head = record.x;                   // >= 0: leaf with that many triangles
+                    payload = record.y;                // first triangle record / children of the first inner child
+                    node_origin = root_origin + make_vec3((float)cx, (float)cy, (float)cz)*node_size;
+                    if (head >= 0) break;
+                    const int first_child = head & 0x7fffff, inner_children = (head >> 23) & 255;
+                    vec3 rc = ray_pos - node_origin;
+                    float half = 0.5f*node_size;
+                    bx = 1 - (rc.x < half); by = 1 - (rc.y < half); bz = 1 - (rc.z < half);
+                    child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
+                    int at = first_child + child_idx;
+                    STACK(depth+1) = at;
+                    cx = (cx << 1) | bx; cy = (cy << 1) | by; cz = (cz << 1) | bz;
+                    node_size *= 0.5f;
+                    depth++;
+                    if ((inner_children >> child_idx) & 1) {
+                        const int block = payload + 8*__popc(inner_children & ((1 << child_idx) - 1));
+                        rc = ray_pos - (root_origin + make_vec3((float)cx, (float)cy, (float)cz)*node_size);
+                        half = 0.5f*node_size;
+                        bx = 1 - (rc.x < half); by = 1 - (rc.y < half); bz = 1 - (rc.z < half);
+                        child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
+                        at = block + child_idx;
+                        STACK(depth+1) = at;
+                        cx = (cx << 1) | bx; cy = (cy << 1) | by; cz = (cz << 1) | bz;
+                        node_size *= 0.5f;
+                        depth++;
+                    }
+                    record = *(const clr_i2u *)(octree_data + 2*at);
+                }
+### else
                 while (depth < LEVELS-1) {
                     head = record.x;                   // >= 0: leaf with that many triangles, -1: inner
                     payload = record.y;                // first triangle record / first child
@@ -377,6 +422,8 @@
                     depth++;
                     if (depth < LEVELS-1) record = *(const clr_i2u *)(octree_data + 2*(payload + child_idx));
                 }
+### endif
+                SPLIT_END(10)     // waiting for the record asked for in the last step + descent
                 t_out = slopes * (node_origin - origin + far_walls*node_size);
                 seg_end = fminf(fminf(t_out.x, t_out.y), t_out.z);
                 if (head > 0) { count = head; first = payload; }
@@ -386,27 +433,29 @@
                 if (seg_end == t_out.x) hx = sx;
                 else if (seg_end == t_out.y) hy = sy;
                 else if (seg_end == t_out.z) hz = sz;
-                while (depth > 0) {
-                    bx += hx; by += hy; bz += hz;
-                    if (bx >= 0 && bx <= 1 && by >= 0 && by <= 1 && bz >= 0 && bz <= 1) break;
-                    depth--;
-                    cx >>= 1; cy >>= 1; cz >>= 1;
-                    bx = cx & 1; by = cy & 1; bz = cz & 1;
-                    node_size *= 2.0f;
+                // The reference walks up level by level until the step stays inside a parent
+                // (Octree.cl:120-140): that many levels as the low bits of the cell coordinate along
+                // the hop are all ones (a step up) or all zeros (a step down) - a carry chain.
+                {
+                    const int along = hx ? cx : (hy ? cy : cz), step_sign = hx + hy + hz;
+                    int up = step_sign > 0 ? __builtin_ctz(~along) : (step_sign < 0 && along ? __builtin_ctz(along) : (step_sign ? 32 : 0));
+                    up = min(up, depth);
+                    depth -= up;
+                    cx >>= up; cy >>= up; cz >>= up;
+                    node_size = ldexpf(node_size, up);
                 }
                 if (depth == 0) last_cell = true;        // leaves the root cube
                 else {
                     // the eight children of a node lie side by side: the neighbour's record is the
                     // old one moved by the difference of the child numbers (no look at the parent)
-                    const int old_idx = ((cx & 1) ? 4 : 0) + ((cy & 1) ? 2 : 0) + ((cz & 1) ? 1 : 0);
-                    cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
-                    child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
-                    const int at = STACK(depth) + (child_idx - old_idx);
+                    cx += hx; cy += hy; cz += hz;
+                    const int at = STACK(depth) + (4*hx + 2*hy + hz);
                     STACK(depth) = at;
                     seg_begin = seg_end;
                     if (seg_begin > t_limit) last_cell = true;
                     else ahead = *(const clr_i2u *)(octree_data + 2*at);
                 }
+                SPLIT_END(11)     // exit distances, hop, request of the next record
             }
 ### endif
             pool_origin[tid] = make_float4(origin.x, origin.y, origin.z, seg_end);
@@ -419,6 +468,7 @@
             if (__any(count > 0)) {
             // bit plane b of the counts is one ballot; the lanes before this one that have the bit
             // set add 2^b to its sum (no LDS traffic, any set of executing lanes)
+            SPLIT_BEGIN();
             int before = 0, total = 0;
             for (int b = 0; __any((count >> b) != 0); ++b) {
                 const unsigned long long plane = __ballot((count >> b) & 1);
@@ -494,6 +544,7 @@
                 ends_below += __popcll(window);
                 return it;
             };
+            SPLIT_END(12)         // prefix sums, range ends, owners
             PoolItem cur = pool_fetch(0);
             for (int base = 0; base < total; base += n_lanes) {
                 const PoolItem next = pool_fetch(base + n_lanes);
@@ -522,6 +573,7 @@
                 }
                 cur = next;
             }
+            SPLIT_END(13)         // the rounds of tests
             }
             PHASE_ADD(7, 1); PHASE_ADD(8, total);
             }
@@ -544,8 +596,17 @@
         PHASE_ADD(0, 1); PHASE_ADD(9, n_lanes);
         ### if obj.profile_phases
         if (rank == 0)
+            for (int slot = 0; slot < 4; ++slot) phase_split[(tid >> 6) * 4 + slot] = 0ull;
+        POOL_SYNC();
+        for (int slot = 0; slot < 4; ++slot) atomicMax(&phase_split[(tid >> 6) * 4 + slot], (unsigned long long)phase_sum[10 + slot]);
+        POOL_SYNC();
+        if (rank == 0) {
             for (int slot = 0; slot < 10; ++slot)
                 atomicAdd(&clr_mesh_phases[(blockIdx.x & 63) * 16 + slot], (unsigned long long)phase_sum[slot]);
+            for (int slot = 0; slot < 4; ++slot)
+                atomicAdd(&clr_mesh_phases[(blockIdx.x & 63) * 16 + 10 + slot], phase_split[(tid >> 6) * 4 + slot]);
+        }
+        POOL_SYNC();
         ### endif
 ### if not obj.ropes
         #undef STACK
@@ -554,6 +615,8 @@
         #undef POOL_WORDS
         #undef PHASE_ADD
         #undef PHASE_END
+        #undef SPLIT_BEGIN
+        #undef SPLIT_END
     ### endcall
 ### endmacro
 
@@ -591,7 +654,6 @@
         #define STACK(level) stack[(level) * 256]
 
         int cx = 0, cy = 0, cz = 0;       // integer cell coordinates at the current depth
-        int bx = 0, by = 0, bz = 0;       // their lowest bits (position inside the parent)
         STACK(0) = root_data_offset;
         int depth = 0;
         uint prev_face = *p_subobject, face = 0;
@@ -618,7 +680,7 @@
                 ### endif
                 const vec3 rc = ray_pos - node_origin;
                 const float half = 0.5f*node_size;
-                bx = 1 - (rc.x < half); by = 1 - (rc.y < half); bz = 1 - (rc.z < half);
+                const int bx = 1 - (rc.x < half), by = 1 - (rc.y < half), bz = 1 - (rc.z < half);
                 child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
                 STACK(depth+1) = payload + child_idx{{ '' if flat else '*2' }};
                 cx = (cx << 1) | bx; cy = (cy << 1) | by; cz = (cz << 1) | bz;
@@ -662,22 +724,23 @@
             else if (seg_end == t_out.y) hy = sy;
             else if (seg_end == t_out.z) hz = sz;
 
-            while (depth > 0) {
-                bx += hx; by += hy; bz += hz;
-                if (bx >= 0 && bx <= 1 && by >= 0 && by <= 1 && bz >= 0 && bz <= 1) break;
-                depth--;
-                cx >>= 1; cy >>= 1; cz >>= 1;
-                bx = cx & 1; by = cy & 1; bz = cz & 1;
-                node_size *= 2.0f;
+            // The reference walks up level by level until the step stays inside a parent
+            // (Octree.cl:120-140): that many levels as the low bits of the cell coordinate along
+            // the hop are all ones (a step up) or all zeros (a step down) - a carry chain.
+            {
+                const int along = hx ? cx : (hy ? cy : cz), step_sign = hx + hy + hz;
+                int up = step_sign > 0 ? __builtin_ctz(~along) : (step_sign < 0 && along ? __builtin_ctz(along) : (step_sign ? 32 : 0));
+                up = min(up, depth);
+                depth -= up;
+                cx >>= up; cy >>= up; cz >>= up;
+                node_size = ldexpf(node_size, up);
             }
             if (depth == 0) return;        // left the root cube
 
             // the eight children of a node lie side by side: the neighbour's record is the old one
             // moved by the difference of the child numbers (no look at the parent)
-            const int old_idx = ((cx & 1) ? 4 : 0) + ((cy & 1) ? 2 : 0) + ((cz & 1) ? 1 : 0);
-            cx = (cx & ~1) | bx; cy = (cy & ~1) | by; cz = (cz & ~1) | bz;
-            child_idx = (bx > 0 ? 4 : 0) + (by > 0 ? 2 : 0) + (bz > 0 ? 1 : 0);
-            STACK(depth) = STACK(depth) + (child_idx - old_idx){{ '' if flat else '*2' }};
+            cx += hx; cy += hy; cz += hz;
+            STACK(depth) = STACK(depth) + (4*hx + 2*hy + hz){{ '' if flat else '*2' }};
 
             seg_begin = seg_end;
             if (seg_begin > t_limit) return;

@@ -112,7 +112,8 @@ class Octree(Tracer):
     MAX_DEPTH = 7
 
     def __init__(self, triangle_mesh, max_depth=3, max_faces_per_leaf=5, builder='python',
-                 layout='stream', max_steps=300, pooled=None, overlap='reference', ropes=None):
+                 layout='stream', max_steps=300, pooled=None, overlap='reference', ropes=None,
+                 two_level=None):
         """builder: 'python' (restatement of the reference's construction) or 'native' (C++
         builder of libclray_hip.so, same tree, any size, max_depth up to 20).
         layout: 'stream' = the reference's integer stream; 'flat' = flattened nodes + per-leaf
@@ -148,6 +149,18 @@ class Octree(Tracer):
         if ropes and not (self.pooled and max_depth <= ROPES_MAX_DEPTH):
             raise RuntimeError("ropes need the pooled traversal and max_depth <= %d" % ROPES_MAX_DEPTH)
         self.ropes = bool(ropes)
+        # pooled traversal only: node records in breadth-first order that also name the children
+        # blocks of a node's inner children (octree_two_level below), so that the descent goes down
+        # two levels per dependent memory access.  Same nodes, same leaves, same table size.
+        # Measured on the 1 M-triangle knot: bit-identical, 1834 -> 1896 Msamples/s
+        # (profiles/r03_mesh_two_level.log).  Default of the pooled traversal; a tree with more
+        # nodes than the record's 23-bit field holds keeps the plain records (_native_data).
+        self._two_level_by_default = two_level is None
+        if two_level is None:
+            two_level = self.pooled and not self.ropes
+        if two_level and not (self.pooled and not self.ropes):
+            raise RuntimeError("two-level records need the pooled traversal without ropes")
+        self.two_level = bool(two_level)
         # development: cycle counters per phase of the pooled traversal (tools/mesh_phases.py)
         self.profile_phases = os.environ.get('CLR_MESH_PROFILE') == '1'
         if self.pooled and layout != 'flat':
@@ -161,10 +174,11 @@ class Octree(Tracer):
         self.max_faces_per_leaf = max_faces_per_leaf
         if self.max_depth >= self.__class__.MAX_DEPTH and builder == 'python':
             raise RuntimeError("max_depth >= MAX_DEPTH")
-        if layout != 'stream' or max_steps != 300 or self.max_depth >= self.__class__.MAX_DEPTH:
-            self.unique_tracer_id = '_%s%s%s_d%d_s%d' % (layout, '_pooled' if self.pooled else '',
-                                                         '_ropes' if self.ropes else '', self.levels, max_steps)
         self.build()
+        if layout != 'stream' or max_steps != 300 or self.max_depth >= self.__class__.MAX_DEPTH:
+            self.unique_tracer_id = '_%s%s%s%s_d%d_s%d' % (layout, '_pooled' if self.pooled else '',
+                                                           '_ropes' if self.ropes else '',
+                                                           '_two' if self.two_level else '', self.levels, max_steps)
 
     @property
     def rope_margin_literal(self):
@@ -278,6 +292,10 @@ class Octree(Tracer):
         self.root = types.SimpleNamespace(origin=self._native['root_origin'], size=self._native['root_size'])
         self.origin, self.size = self.root.origin, self.root.size
         self.n_leaves = self._native['n_leaves']
+        if self.two_level and numpy.asarray(self._native['flat_nodes']).size // 2 >= TWO_LEVEL_MAX_NODES:
+            if not self._two_level_by_default:
+                raise RuntimeError("two-level records hold up to 2^23 nodes")
+            self.two_level = False
 
     def _native_data(self):
         native = self._native
@@ -295,7 +313,7 @@ class Octree(Tracer):
             packed = numpy.ascontiguousarray(recs[:, :, :3]).reshape(-1)
             packed = numpy.concatenate([packed, numpy.zeros((-packed.size) % 4, dtype=numpy.float32)])
             data['vector'] = numpy.vstack([vectors, packed.reshape(-1, 4)])
-            nodes = native['flat_nodes'].ravel()
+            nodes = (octree_two_level(native['flat_nodes']) if self.two_level else native['flat_nodes']).ravel()
             self.flat_ids_offset = nodes.size
             tables = [faces, nodes, face_ids]
             self.flat_rope_offset = self.flat_parent_offset = 0
@@ -373,6 +391,51 @@ class Octree(Tracer):
 
 
 ROPES_MAX_DEPTH = 9
+TWO_LEVEL_MAX_NODES = 1 << 23
+
+
+def octree_two_level(flat_nodes):
+    """The node records of a flattened octree (rows (head, payload), octree_cells above) in
+    breadth-first order and with inner nodes written as
+        head    = 1 << 31 | (bit c set: child c is an inner node) << 23 | first child record
+        payload = first record of the children of the first inner child,
+    the children blocks of a node's inner children lying back to back in child order (breadth-first
+    order does that).  From one such record the traversal knows where the grandchild under a point
+    is without reading the child's record (hip_templates/shapes/meshes.hip, two_level): one
+    dependent memory access per two levels of the reference's descent
+    (cl_templates/objects/Octree.cl:120-160), the same nodes visited.  Leaves keep (number of
+    triangles, first triangle record)."""
+    nodes = numpy.asarray(flat_nodes, dtype=numpy.int64).reshape(-1, 2)
+    n = nodes.shape[0]
+    if n >= TWO_LEVEL_MAX_NODES:
+        raise RuntimeError("octree_two_level: more than 2^23 nodes")
+    is_inner = nodes[:, 0] == -1
+    order = [numpy.array([0], dtype=numpy.int64)]
+    while order[-1].size:
+        level = order[-1]
+        inner = level[is_inner[level]]
+        order.append((nodes[inner, 1][:, None] + numpy.arange(8)[None, :]).ravel())
+    order = numpy.concatenate(order)
+    if order.size != n or numpy.unique(order).size != n:
+        raise RuntimeError("octree_two_level: the records do not form one tree")
+    new_index = numpy.empty(n, dtype=numpy.int64)
+    new_index[order] = numpy.arange(n)
+
+    out = nodes[order].copy()
+    inner = numpy.nonzero(is_inner[order])[0]                 # new indices of the inner nodes
+    old_children = nodes[order[inner], 1][:, None] + numpy.arange(8)[None, :]
+    first_child = new_index[old_children[:, 0]]
+    assert numpy.array_equal(new_index[old_children], first_child[:, None] + numpy.arange(8)[None, :])
+    child_inner = is_inner[old_children]
+    mask = (child_inner << numpy.arange(8)[None, :]).sum(axis=1)
+    # children blocks of the inner children: back to back, in child order
+    blocks = numpy.where(child_inner, new_index[numpy.where(child_inner, nodes[old_children, 1], 0)], -1)
+    rank = numpy.cumsum(child_inner, axis=1) - child_inner
+    first_block = numpy.where(child_inner.any(axis=1), blocks.max(axis=1, initial=-1, where=child_inner & (rank == 0)), 0)
+    assert numpy.array_equal(blocks[child_inner], (first_block[:, None] + 8 * rank)[child_inner])
+    out[inner, 0] = -(1 << 31) + (mask << 23) + first_child
+    out[inner, 1] = first_block
+    return out.astype(numpy.int32)
 
 
 def octree_cells(flat_nodes):

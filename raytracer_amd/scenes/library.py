@@ -365,7 +365,7 @@ def mesh_through_off_file(vertices, faces, path):
 
 
 def scene_mesh(n_u=1000, n_v=500, layout='flat', max_depth=None, max_faces_per_leaf=8,
-               max_steps=2000, material='white', pooled=None, overlap='sat', mesh=None, via_off=None, ropes=None):
+               max_steps=2000, material='white', pooled=None, overlap='sat', mesh=None, via_off=None, ropes=None, two_level=None):
     """overlap: how the builder files faces under leaves - 'sat' (triangle against box, 3.0 leaf
     records per face on this mesh) or 'reference' (the reference's bounding-sphere rule, 12.7);
     the hits are the same (tests/test_gpu_parity.py).
@@ -383,7 +383,7 @@ def scene_mesh(n_u=1000, n_v=500, layout='flat', max_depth=None, max_faces_per_l
                         auto_flip_normal=True)
     s.add_object(Octree(mesh, max_depth=max_depth, max_faces_per_leaf=max_faces_per_leaf,
                         builder='native', layout=layout, max_steps=max_steps, pooled=pooled,
-                        overlap=overlap, ropes=ropes), material, 'knot')
+                        overlap=overlap, ropes=ropes, two_level=two_level), material, 'knot')
     s.image.size = (1920, 1080)
     s.samples_per_pixel = 16
     s.max_bounces = 4

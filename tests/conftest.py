@@ -35,7 +35,7 @@ def load_scene(name, size=None, **overrides):
                                     Cylinder=shapes.Cylinder, HalfSpace=shapes.HalfSpace)
         scene = golden_scenes.VARIANTS[name](api)
     elif name.startswith('scene-mesh'):
-        # 'scene-mesh:<n_u>x<n_v>:<layout>:<overlap>', layout 'flat-lanes' = flat, not pooled, 'flat-ropes';
+        # 'scene-mesh:<n_u>x<n_v>:<layout>:<overlap>', layout 'flat-lanes' = flat, not pooled, 'flat-ropes', 'flat-two';
         # overlap 'reference' (default here: the reference's tree) or 'sat'
         parts = name.split(':')[1:]
         grid, layout, overlap = parts + ['120x60', 'flat', 'reference'][len(parts):]
@@ -45,8 +45,12 @@ def load_scene(name, size=None, **overrides):
             scene = make(n_u, n_v, layout='flat', pooled=False, overlap=overlap)
         elif layout == 'flat-ropes':        # pooled tests, next leaf through neighbour links
             scene = make(n_u, n_v, layout='flat', pooled=True, ropes=True, overlap=overlap)
+        elif layout == 'flat-two':          # pooled tests, node records for a two-level descent
+            scene = make(n_u, n_v, layout='flat', pooled=True, two_level=True, overlap=overlap)
+        elif layout == 'flat':              # pooled tests, plain node records
+            scene = make(n_u, n_v, layout='flat', pooled=True, two_level=False, overlap=overlap)
         else:
-            scene = make(n_u, n_v, layout=layout, overlap=overlap, pooled=True if layout == 'flat' else None)
+            scene = make(n_u, n_v, layout=layout, overlap=overlap)
     else:
         scene = runpy.run_path(os.path.join(SCENE_DIR, name + '.py'))['scene']
     if size is not None:

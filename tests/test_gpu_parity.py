@@ -156,7 +156,7 @@ def test_interleaved_band_tiles_reassemble_the_frame(rng_mode):
     assert np.array_equal(bits(frame[shard.gather_index()]), bits(want))
 
 
-@pytest.mark.parametrize('flat_layout', ['flat', 'flat-lanes', 'flat-ropes'])
+@pytest.mark.parametrize('flat_layout', ['flat', 'flat-lanes', 'flat-ropes', 'flat-two'])
 def test_flattened_octree_matches_reference_stream_and_oracle(flat_layout):
     """BASELINE config C4 at reduced size (14 400 triangles): the flattened HBM layout with the
     LDS stack (triangle tests pooled over the wave, or per lane), the reference-stream layout
@@ -165,6 +165,7 @@ def test_flattened_octree_matches_reference_stream_and_oracle(flat_layout):
     flat = Renderer(load_scene('scene-mesh:120x60:' + flat_layout, (96, 64)), seed=4)
     assert ('pool_best' in flat.program_code) == (flat_layout != 'flat-lanes')
     assert ('node_ropes' in flat.program_code) == (flat_layout == 'flat-ropes')
+    assert ('inner_children' in flat.program_code) == (flat_layout == 'flat-two')
     stream = Renderer(load_scene('scene-mesh:120x60:stream', (96, 64)), seed=4)
     osc = oracle.OracleScene(stream)
     tape = flat.make_tape(0, 4)
@@ -746,9 +747,11 @@ def test_one_million_triangles_pooled_per_lane_and_both_trees_agree():
     properties.  First-hit ids, distances and normals of the full frame are bit-identical between
     the pooled and the per-lane triangle tests and between the triangle-box tree and the
     reference-rule tree, and with the next leaf found through neighbour links (ropes) instead of the
-    reference's descent; a 2-pass image is bit-identical between pooled, per-lane and ropes."""
+    reference's descent, or with node records that take the descent down two levels per access; a
+    2-pass image is bit-identical between pooled, per-lane, ropes and two-level records."""
     results, images = [], []
-    for layout, overlap in (('flat', 'sat'), ('flat-lanes', 'sat'), ('flat', 'reference'), ('flat-ropes', 'sat')):
+    for layout, overlap in (('flat', 'sat'), ('flat-lanes', 'sat'), ('flat', 'reference'), ('flat-ropes', 'sat'),
+                            ('flat-two', 'sat')):
         r = Renderer(load_scene('scene-mesh:1000x500:%s:%s' % (layout, overlap), (1920, 1080)), seed=9)
         tape = r.make_tape(0, 2)
         results.append(r.first_hit(tuple(x[:1] if x is not None else None for x in tape)))
@@ -761,7 +764,7 @@ def test_one_million_triangles_pooled_per_lane_and_both_trees_agree():
     assert 0 < knot.mean() < 1 and len(np.unique(ids0[:, 1])) > 10000    # thousands of distinct faces seen
     for ids, t, n in results[1:]:
         assert np.array_equal(ids, ids0) and np.array_equal(bits(t), bits(t0)) and np.array_equal(bits(n), bits(n0))
-    assert images[0][:, :3].mean() > 0 and len(images) == 3
+    assert images[0][:, :3].mean() > 0 and len(images) == 4
     for img in images[1:]:
         assert np.array_equal(bits(images[0]), bits(img))
 

@@ -197,3 +197,46 @@ def test_ropes_visit_the_leaves_of_the_reference_descent(grid, n_rays):
     assert total_leaves > 10 * n_rays
     print('%d leaves visited, %d hops took the fallback; shortcut: %s' % (total_leaves, total_fallbacks, SHORTCUT))
     assert SHORTCUT['sure'] > 5 * SHORTCUT['checked'] > 0
+
+
+def test_two_level_records_describe_the_same_tree():
+    """objects/meshes.py: octree_two_level - breadth-first records in which an inner node names the
+    children blocks of its inner children.  Every root-to-leaf path of child numbers ends in the
+    same (triangle count, first triangle record) as in the builder's records, reached through the
+    two-level rule of the pooled traversal (hip_templates/shapes/meshes.hip), and the child's own
+    record names the block the parent's record promises."""
+    from raytracer_amd.objects.meshes import octree_two_level
+    plain = np.asarray(knot_tree(120, 60, two_level=False)._native['flat_nodes']).reshape(-1, 2)
+    wide = octree_two_level(plain)
+    assert wide.shape == plain.shape and wide.dtype == np.int32
+
+    def leaves_plain():
+        todo = [(0, ())]
+        while todo:
+            at, path = todo.pop()
+            head, payload = (int(v) for v in plain[at])
+            if head >= 0:
+                yield path, (head, payload)
+            else:
+                todo += [(payload + c, path + (c,)) for c in range(8)]
+
+    def leaves_wide():
+        todo = [(0, ())]
+        while todo:
+            at, path = todo.pop()
+            head, payload = (int(v) for v in wide[at])
+            if head >= 0:
+                yield path, (head, payload)
+                continue
+            first_child, inner_children = head & 0x7fffff, (head >> 23) & 255
+            for c in range(8):
+                if (inner_children >> c) & 1:
+                    block = payload + 8 * bin(inner_children & ((1 << c) - 1)).count('1')
+                    assert wide[first_child + c, 0] < 0 and (int(wide[first_child + c, 0]) & 0x7fffff) == block
+                    todo += [(block + c2, path + (c, c2)) for c2 in range(8)]
+                else:
+                    assert wide[first_child + c, 0] >= 0
+                    todo.append((first_child + c, path + (c,)))
+
+    a, b = dict(leaves_plain()), dict(leaves_wide())
+    assert len(a) > 1000 and a == b
