@@ -518,7 +518,7 @@
             // while the record of item w is on its way from memory, the owner of item w + n_lanes
             // is looked up and its record requested.  Rounds are fetched in order: `ends_below`
             // counts the range ends before the round being fetched.
-            struct PoolItem { int owner, record, face; clr_f4u r0, r1; float r2; };   // owner < 0: none
+            struct PoolItem { int owner, record; clr_f4u r0, r1; float r2; };   // owner < 0: none
             int ends_below = 0;
             const unsigned long long round_lanes = n_lanes == 64 ? ~0ull : (1ull << n_lanes) - 1ull;
             const unsigned long long ranks_before = (1ull << rank) - 1ull;
@@ -538,8 +538,6 @@
                     const float * __restrict__ rec = tris + 9*record;
                     it.r0 = *(const clr_f4u *)rec; it.r1 = *(const clr_f4u *)(rec + 4);
                     it.r2 = rec[8];
-                    // the face number matters only to a ray that starts on a face of this mesh
-                    it.face = __float_as_int(pool_ray[it.owner].w) < 0 ? -2 : tri_ids[record];
                 }
                 ends_below += __popcll(window);
                 return it;
@@ -550,7 +548,7 @@
                 const PoolItem next = pool_fetch(base + n_lanes);
                 float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = o4;
                 if (cur.owner >= 0) { o4 = pool_origin[cur.owner]; d4 = pool_ray[cur.owner]; }
-                if (cur.owner >= 0 && cur.face != __float_as_int(d4.w)) {
+                if (cur.owner >= 0) {
                     const vec3 o_ray = make_vec3(d4), o_origin = make_vec3(o4);
                     const vec3 va = make_vec3(cur.r0.x, cur.r0.y, cur.r0.z);
                     const vec3 e1 = make_vec3(cur.r0.w, cur.r1.x, cur.r1.y);
@@ -565,7 +563,10 @@
                         const float v = dot(o_ray, qvec) * inv_det;
                         if (!(v < 0.f || u + v > 1.f)) {
                             const float t = dot(e2, qvec) * inv_det;
-                            if (t > 0.0f && t < o4.w)
+                            // the face the ray starts on is left out (TriangleMesh.cl:20): looked at
+                            // only here, for the few items that got this far - a skipped triangle
+                            // and a tested one whose hit is dropped leave the same minimum
+                            if (t > 0.0f && t < o4.w && (__float_as_int(d4.w) < 0 || tri_ids[cur.record] != __float_as_int(d4.w)))
                                 atomicMin(&pool_best[cur.owner],
                                           ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)cur.record);
                         }
