@@ -543,9 +543,7 @@
                 return it;
             };
             SPLIT_END(12)         // prefix sums, range ends, owners
-            PoolItem cur = pool_fetch(0);
-            for (int base = 0; base < total; base += n_lanes) {
-                const PoolItem next = pool_fetch(base + n_lanes);
+            auto pool_test = [&](const PoolItem &cur) {
                 float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = o4;
                 if (cur.owner >= 0) { o4 = pool_origin[cur.owner]; d4 = pool_ray[cur.owner]; }
                 if (cur.owner >= 0) {
@@ -572,6 +570,11 @@
                         }
                     }
                 }
+            };
+            PoolItem cur = pool_fetch(0);
+            for (int base = 0; base < total; base += n_lanes) {
+                const PoolItem next = pool_fetch(base + n_lanes);
+                pool_test(cur);
                 cur = next;
             }
             SPLIT_END(13)         // the rounds of tests

@@ -161,6 +161,8 @@ class Octree(Tracer):
         if two_level and not (self.pooled and not self.ropes):
             raise RuntimeError("two-level records need the pooled traversal without ropes")
         self.two_level = bool(two_level)
+        # development: code-generation variants under measurement (CLR_VARIANTS, as Renderer.variants)
+        self.variants = frozenset(filter(None, os.environ.get('CLR_VARIANTS', '').split(',')))
         # development: cycle counters per phase of the pooled traversal (tools/mesh_phases.py)
         self.profile_phases = os.environ.get('CLR_MESH_PROFILE') == '1'
         if self.pooled and layout != 'flat':
