@@ -77,6 +77,12 @@ CLR_FN float clr_quotient_short(float a, float d, float y) {
     return __builtin_fmaf(r, y, q);
 }
 
+// The one division inside clr_logf (clr_math.inl), f / (2 + f) with f = m - 1, m a binary32 number in
+// [sqrt(1/2), sqrt(2)): f is 0 or at least 2^-24 in magnitude and the divisor lies in [1.7, 2.42], so
+// the operands are inside the range of the short sequence by construction (all 2^23 values of m are
+// checked against the compiler's division in tests/test_gpu_exact_math.py).
+CLR_FN float clr_log_quotient(const float a, const float d) { return clr_quotient_short(a, d, clr_reciprocal_short(d)); }
+
 // Square root where no guard is at hand (marching loops): the short sequence inside its range,
 // tested on the spot, the generic expansion outside it (and for NaNs).  Same bits either way.
 CLR_FN float clr_sqrt_ranged(float x) {

@@ -65,7 +65,6 @@ static __device__ const clr_guard_safe clr_g = {};
 
 #define CLR_MATH_FN CLR_FN
 // the one division inside clr_logf: operands inside the range of the short sequence by construction
-CLR_FN float clr_log_quotient(const float a, const float d) { return clr_quotient_short(a, d, clr_reciprocal_short(d)); }
 #define CLR_LOG_QUOTIENT(a, d) clr_log_quotient((a), (d))
 {% include 'clr_math.inl' %}
 {% include 'clr_rng.inl' %}

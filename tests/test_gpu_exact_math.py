@@ -79,6 +79,26 @@ extern "C" __global__ void check_exact(uint *out, int iterations, int mode, int 
     for (int k = 0; k < 3; k++) atomicAdd(out + 3 + k, accepted[k] >> 4);
 }
 
+// clr_sqrt_ranged against sqrtf on raw bit patterns and on exponents around its range limits;
+// clr_log_quotient against the compiler's division on every operand pair clr_logf can hand it
+// (clr_math.inl: m = bits + 0x3f3504f3 for the 2^23 mantissa patterns, f = m - 1, f / (2 + f))
+extern "C" __global__ void check_ranged(uint *out, int iterations, uint seed) {
+    const uint tid = blockIdx.x * blockDim.x + threadIdx.x, threads = gridDim.x * blockDim.x;
+    uint s = tid * 2654435761u + seed;
+    if (s == 0) s = 1;
+    for (int i = 0; i < iterations; i++) {
+        const float a = draw(s, i & 1, 126);
+        const float r = clr_sqrt_ranged(a);
+        if (!same(r, sqrtf(a))) report(out, 0, a, 0.0f, r, sqrtf(a));
+    }
+    for (uint k = tid; k < (1u << 23); k += threads) {
+        const float f = __uint_as_float(k + 0x3f3504f3u) - 1.0f, d = 2.0f + f;
+        const float q = clr_log_quotient(f, d);
+        if (!same(q, f / d)) report(out, 1, f, d, q, f / d);
+        if (k == 0 || k == (1u << 23) - 1) atomicAdd(out + 3, 1u);     // both ends of the enumeration were reached
+    }
+}
+
 // generic arithmetic through the same interface must be the plain operators
 extern "C" __global__ void eval_safe(const float *a, const float *b, float *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,3 +148,17 @@ def test_safe_guard_is_the_plain_operator(acc):
         want = np.concatenate([a / b, np.sqrt(np.abs(a))]).astype(np.float32)
     both_nan = np.isnan(got) & np.isnan(want)
     assert ((got.view(np.uint32) == want.view(np.uint32)) | both_nan).all()
+
+
+def test_ranged_square_root_and_the_logarithms_quotient(acc):
+    """clr_sqrt_ranged (the Julia-set marcher's lengths) equals sqrtf on 2^28 operands, half raw bit
+    patterns, half spread over all exponents; clr_log_quotient equals the compiler's division on
+    every one of the 2^23 operand pairs that clr_logf can produce."""
+    out = acc.new_array((32,), np.uint32, zeros=True)
+    threads, iterations = 1 << 18, 1 << 10
+    acc.call('check_ranged', threads, (out,), value_args=(np.int32(iterations), np.uint32(777)))
+    res = out.get()
+    detail = {name: res[8 + 4*k: 12 + 4*k].view(np.float32).tolist()
+              for k, name in enumerate(('sqrt', 'log quotient')) if res[k]}
+    assert res[:2].sum() == 0, "mismatches %s, first (a, b, got, want): %s" % (res[:2].tolist(), detail)
+    assert res[3] == 2
