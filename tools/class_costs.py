@@ -19,10 +19,15 @@ passes = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 hint = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 
 
+def label(index, obj):
+    """the object's name, or class and material where the scene gives none"""
+    return obj.name or '%s-%s-%d' % (obj.tracer.__class__.__name__, obj.material, index)
+
+
 def timed(without=None):
     scene = load_scene(name, size)
     if without is not None:
-        scene.objects[:] = [o for o in scene.objects if o.name != without]
+        scene.objects[:] = [o for i, o in enumerate(scene.objects) if label(i, o) != without]
     r = Renderer(scene, seed=0, min_waves_per_simd=hint)
     tape = r.make_tape(0, passes)
     r.upload_tape(tape)
@@ -34,7 +39,8 @@ def timed(without=None):
 
 full, regs, spills = timed()
 print('%s %dx%d, %d passes, hint %d: %.3f ms per launch (%s registers, %s spilled)' % (name, size[0], size[1], passes, hint, full, regs, spills), flush=True)
-names = [o.name for o in load_scene(name, size).objects if o.name not in ('wall', 'floor', 'ceiling', 'light', None)]
+names = [label(i, o) for i, o in enumerate(load_scene(name, size).objects)
+         if o.name not in ('wall', 'floor', 'ceiling', 'light') and o.material != 'sky']
 rows = []
 for shape in names:
     ms, regs, spills = timed(shape)
