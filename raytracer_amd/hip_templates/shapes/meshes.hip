@@ -404,7 +404,7 @@
                         node_size *= 0.5f;
                         depth++;
                     }
-                    record = *(const clr_i2u *)(octree_data + 2*at);
+                    record = *(const clr_i2u *)((const char *)octree_data + 8u*(unsigned)at);
                 }
 ### else
                 while (depth < LEVELS-1) {
@@ -453,7 +453,7 @@
                     STACK(depth) = at;
                     seg_begin = seg_end;
                     if (seg_begin > t_limit) last_cell = true;
-                    else ahead = *(const clr_i2u *)(octree_data + 2*at);
+                    else ahead = *(const clr_i2u *)((const char *)octree_data + 8u*(unsigned)at);
                 }
                 SPLIT_END(11)     // exit distances, hop, request of the next record
             }
@@ -535,9 +535,11 @@
                     const int2 owner = pool_owner[wave_base + q];
                     it.owner = owner.x;
                     const int record = it.record = w + owner.y;
-                    const float * __restrict__ rec = tris + 9*record;
-                    it.r0 = *(const clr_f4u *)rec; it.r1 = *(const clr_f4u *)(rec + 4);
-                    it.r2 = rec[8];
+                    // 32-bit byte offsets from the uniform base (scalar base + vector offset addressing;
+                    // 36 B records: up to 119 M of them, checked where the data is packed)
+                    const char * __restrict__ rec = (const char *)tris + 36u*(unsigned)record;
+                    it.r0 = *(const clr_f4u *)rec; it.r1 = *(const clr_f4u *)(rec + 16);
+                    it.r2 = *(const float *)(rec + 32);
                 }
                 ends_below += __popcll(window);
                 return it;

@@ -313,6 +313,8 @@ class Octree(Tracer):
             recs = numpy.asarray(native['flat_tris'], dtype=numpy.float32).reshape(-1, 3, 4)
             face_ids = numpy.ascontiguousarray(recs[:, 0, 3]).view(numpy.int32)
             packed = numpy.ascontiguousarray(recs[:, :, :3]).reshape(-1)
+            if self.pooled and (packed.size * 4 >= 1 << 32 or numpy.asarray(native['flat_nodes']).size * 4 >= 1 << 32):
+                raise RuntimeError("the pooled traversal addresses its tables with 32-bit byte offsets: under 4 GB each")
             packed = numpy.concatenate([packed, numpy.zeros((-packed.size) % 4, dtype=numpy.float32)])
             data['vector'] = numpy.vstack([vectors, packed.reshape(-1, 4)])
             nodes = (octree_two_level(native['flat_nodes']) if self.two_level else native['flat_nodes']).ravel()
