@@ -147,6 +147,25 @@ CLR_FN bool clr_unit_sphere_may_be_hit(const vec3 o, const vec3 d) {
     return !(heading_away || passing_by);
 }
 
+// Bodies bounded by planes (objects/convex.py: plane_body_cull_ball).  `o` = the local origin
+// relative to the centre of the ball, d = the un-normalised local ray, rho2 = the squared radius of
+// the culling ball (1.25 x the radius of a ball that holds the body, and 5 % for the roundings
+// here), limit = the distance up to which a hit counts.  False only where the reference's component
+// tests are known to end without a hit whatever their roundings: the origin is within 64 radii,
+// the stretch looked at is shorter than 256 radii, and the ray stays outside the ball on it -
+// then every point of the stretch violates one of the body's planes by at least a quarter of the
+// centre's distance from it (>= 1/80 of the body's radius), which is 80 x what the roundings of
+// slope, offset and quotient can move a computed crossing.  NaNs and
+// infinities take the full test.
+CLR_FN bool clr_ball_may_be_hit(const vec3 o, const vec3 d, const float rho2, const float limit) {
+    const float od = dot(o, d), oo = dot(o, o), dd = dot(d, d);
+    if (!(oo > rho2 && oo < 0x1p+12f * rho2 && dd > 0x1p-60f && dd < 0x1p+60f)) return true;
+    if (!(limit * limit * dd < 0x1p+16f * rho2)) return true;
+    const bool heading_away = od > 0.0f && od * od > 0x1p-36f * (dd * oo);
+    const bool passing_by = oo * dd - od * od > rho2 * dd;
+    return !(heading_away || passing_by);
+}
+
 // ---- quaternions (static.cl:87-101): x = real part
 CLR_FN vec4 quaternion_mult(vec4 q1, vec4 q2) {
     vec3 v1 = make_vec3(q1.y, q1.z, q1.w), v2 = make_vec3(q2.y, q2.z, q2.w);

@@ -92,6 +92,55 @@ class ConvexIntersection(Tracer):
         return values
 
 
+CULL_BALL_FACTOR = 1.25      # radius of the culling ball / radius of the ball that holds the body
+CULL_BALL_SLACK = 1.05       # on the squared radius: rounding of the test itself
+CULL_MIN_MARGIN = 0.05       # least distance of the centre from a bounding plane / radius of the body
+
+
+def plane_body_cull_ball(components):
+    """(centre, squared radius of the culling ball) in tracer coordinates for a body bounded by
+    planes only (LayerComponent / HalfSpaceComponent), or None.  A ray that stays outside that ball
+    on the stretch the tracer looks at is known to end the reference's component tests without a
+    hit, whatever their roundings (clr_ball_may_be_hit)."""
+    import itertools
+    planes = []
+    for c in components:
+        if not isinstance(c, HalfSpaceComponent):
+            return None
+        n = numpy.ravel(numpy.asarray(c.normal, dtype=float))
+        if abs(numpy.linalg.norm(n) - 1.0) > 1e-6:
+            return None
+        offset = float(numpy.dot(numpy.ravel(numpy.asarray(c.position, dtype=float)), n))
+        planes.append((n, offset + c.h))
+        if isinstance(c, LayerComponent):
+            planes.append((-n, -offset))
+    normals = numpy.array([n for n, _ in planes])
+    heights = numpy.array([d for _, d in planes])
+    scale = max(1.0, numpy.abs(heights).max())
+    vertices = []
+    for i, j, k in itertools.combinations(range(len(planes)), 3):
+        m = normals[[i, j, k]]
+        if abs(numpy.linalg.det(m)) < 1e-9:
+            continue
+        x = numpy.linalg.solve(m, heights[[i, j, k]])
+        if (normals.dot(x) <= heights + 1e-9 * scale).all():
+            vertices.append(x)
+    if len(vertices) < 4:
+        return None
+    vertices = numpy.array(vertices)
+    centre = 0.5 * (vertices.min(axis=0) + vertices.max(axis=0))
+    radius = float(numpy.linalg.norm(vertices - centre, axis=1).max()) * (1.0 + 1e-6)
+    margins = heights - normals.dot(centre)
+    if radius <= 0 or margins.min() < CULL_MIN_MARGIN * radius:
+        return None
+    # an unbounded body has no vertex in some direction: every direction must meet a plane
+    probe = numpy.random.RandomState(0).normal(size=(256, 3))
+    probe /= numpy.linalg.norm(probe, axis=1)[:, None]
+    if ((normals.dot(probe.T) > 1e-3).sum(axis=0) == 0).any():
+        return None
+    return centre, (CULL_BALL_FACTOR * radius) ** 2 * CULL_BALL_SLACK
+
+
 class UniqueConvexIntersection(ConvexIntersection):
     """All component parameters baked into the generated source as literals."""
 
@@ -124,6 +173,16 @@ class FixedConvexIntersection(UniqueConvexIntersection):
     def __init__(self, *args, **kwargs):
         UniqueConvexIntersection.__init__(self, *args, **kwargs)
         self.unique_tracer_id = ''
+
+    @property
+    def can_hit_expression(self):
+        """Bodies bounded by planes: the ray against a ball around the body (literals of the class)."""
+        ball = plane_body_cull_ball(self.components)
+        if ball is None:
+            return None
+        centre, rho2 = ball
+        where = 'local_pos' if numpy.linalg.norm(centre) < 1e-12 else 'local_pos - %s' % vec_literal(centre)
+        return '(within || clr_ball_may_be_hit(%s, local_ray, %s, isec_dist))' % (where, float_literal(rho2))
 
 
 class PolyhedronLight:

@@ -1020,6 +1020,84 @@ def test_sphere_miss_test_agrees_with_the_full_test_on_grazing_rays():
     assert np.array_equal(bits(r.img.get()), bits(oimg))
 
 
+def test_ball_cull_of_plane_bounded_bodies_agrees_with_the_full_test():
+    """FixedConvexIntersection.can_hit_expression (static.hip, clr_ball_may_be_hit): a body bounded
+    by planes is dropped before the ray is normalised only where the reference's component tests
+    cannot find a hit.  Three bodies (a dodecahedron, a tetrahedron turned and stretched, a small
+    cube) and rays aimed at the silhouette of each one's culling ball within 0, +-1e-7 ... +-1e-2
+    radii of the tangent, at the silhouette of the ball that just holds the body, into the body, and
+    rays that leave at right angles to the line to the centre, +- the same: first-hit object, face, distance
+    and normal equal the oracle's full test bit for bit; so do a few passes of the estimator."""
+    import re
+    from oracle import oracle
+    from raytracer_amd.objects import Dodecahedron, Tetrahedron, Cube
+    from raytracer_amd.objects.convex import CULL_BALL_FACTOR, CULL_BALL_SLACK
+    from raytracer_amd.scenes.default_scenes import BoxScene
+    s = BoxScene()
+    s.image.size = (256, 96)
+    turned = Tetrahedron((0.6, 1.2, 0.8), 0.4)
+    turned.rotate(axis=(1, 2, 3), deg=37)
+    turned.linear_transform(scaling=(1.0, 1.3, 0.8))
+    bodies = [Dodecahedron((-1.0, 0.5, 1.0), 0.6), turned, Cube((1.5, 2.0, 2.2), 0.1)]
+    for tracer in bodies:
+        assert 'clr_ball_may_be_hit' in tracer.can_hit_expression
+        s.add_object(tracer, 'white')
+    r = Renderer(s, seed=2, split_passes=False)
+    assert r.program_code.count('clr_ball_may_be_hit(') >= 7      # the definition, trace and shadow step of three classes
+    origin = np.array(s.camera_position, dtype=np.float64)
+    rng = np.random.RandomState(78)
+    offsets = np.concatenate([[0.0], np.ravel([[d, -d] for d in (1e-7, 3e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2)])])
+    rays = []
+    while len(rays) < r.n_pixels:
+        tracer = bodies[len(rays) % 3]
+        rho = np.sqrt(float(re.search(r', ([0-9.e+-]+)f, isec_dist', tracer.can_hit_expression).group(1)))
+        to_world = tracer.global_to_tracer_coordinate_transform()
+        linear = np.asarray(to_world.linear, dtype=np.float64)
+        centre = np.ravel(np.asarray(to_world.translation, dtype=np.float64))
+        # a world direction whose local image has length 1: scale the aim so that the LOCAL ray is
+        # tangent to the local ball (the bodies are stretched: work in tracer coordinates)
+        inverse = np.linalg.inv(linear)
+        o_local = inverse.dot(origin - centre)
+        dist = np.linalg.norm(o_local)
+        axis = -o_local / dist
+        side = np.cross(axis, rng.normal(size=3))
+        side /= np.linalg.norm(side)
+        delta = offsets[rng.randint(len(offsets))]
+        kind = (len(rays) // 3) % 4
+        if kind == 3:      # into the body, anywhere up to the ball that holds it
+            sin_a = min(rho / np.sqrt(CULL_BALL_SLACK) / CULL_BALL_FACTOR * rng.uniform(0.0, 1.0) / dist, 1.0)
+            local = axis * np.sqrt(1.0 - sin_a ** 2) + side * sin_a
+        elif kind == 0:    # tangent to the culling ball, moved by delta radii
+            sin_a = min(rho * (1.0 + delta) / dist, 1.0)
+            local = axis * np.sqrt(1.0 - sin_a ** 2) + side * sin_a
+        elif kind == 1:    # tangent to the ball that just holds the body
+            sin_a = min(rho / np.sqrt(CULL_BALL_SLACK) / CULL_BALL_FACTOR * (1.0 + delta) / dist, 1.0)
+            local = axis * np.sqrt(1.0 - sin_a ** 2) + side * sin_a
+        else:              # at right angles to the line to the centre, tilted by delta
+            local = side + axis * delta
+        direction = linear.dot(local)
+        rays.append(direction / np.linalg.norm(direction))
+    cam = np.zeros((r.n_pixels, 4), dtype=np.float32)
+    cam[:, :3] = np.array(rays)[:r.n_pixels]
+    r.host_cam = cam
+    r.cam.set(cam)
+    tape = r.make_tape(0, 1)
+    tape[0][0, 0:3, :] = 0.0
+    tape[0][0, 0:3, 0:3] = np.eye(3)                  # no jitter: the crafted directions as they are
+    tape[0][0, 3, :] = 0.0
+    tape[0][0, 4, 0:3] = origin
+    ids, t, normal = r.first_hit(tape)
+    oids, ot, onormal = oracle.OracleScene(r).first_hit(tape)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(normal), bits(onormal))
+    hit = np.isin(oids[:, 0], [i + 1 for i, obj in enumerate(s.objects) if obj.tracer in bodies])
+    assert 0.1 < hit.mean() < 0.3, hit.mean()          # a quarter of the rays are aimed into the bodies
+    more = r.make_tape(1, 3)
+    r.render_tape(more)
+    oimg, _, _ = oracle.OracleScene(r).render(more)
+    assert np.array_equal(bits(r.img.get()), bits(oimg))
+
+
 def test_plane_distance_test_agrees_with_the_full_test_on_near_ties():
     """HalfSpace.can_hit_expression, second part (static.hip, clr_plane_before): a plane is dropped
     before the ray is normalised only where the full test cannot put it below the distance that
