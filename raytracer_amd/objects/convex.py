@@ -133,11 +133,19 @@ def plane_body_cull_ball(components):
     margins = heights - normals.dot(centre)
     if radius <= 0 or margins.min() < CULL_MIN_MARGIN * radius:
         return None
-    # an unbounded body has no vertex in some direction: every direction must meet a plane
-    probe = numpy.random.RandomState(0).normal(size=(256, 3))
-    probe /= numpy.linalg.norm(probe, axis=1)[:, None]
-    if ((normals.dot(probe.T) > 1e-3).sum(axis=0) == 0).any():
+    # The vertices say nothing about a body that is unbounded: it is bounded iff each coordinate
+    # has a finite maximum and minimum over it (a direction of recession has a non-zero component).
+    try:
+        from scipy.optimize import linprog
+    except ImportError:
         return None
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            cost = numpy.zeros(3)
+            cost[axis] = -sign
+            result = linprog(cost, A_ub=normals, b_ub=heights, bounds=[(None, None)] * 3, method='highs')
+            if result.status != 0 or abs(result.x[axis] - centre[axis]) > radius * (1.0 + 1e-6):
+                return None
     return centre, (CULL_BALL_FACTOR * radius) ** 2 * CULL_BALL_SLACK
 
 
@@ -177,10 +185,11 @@ class FixedConvexIntersection(UniqueConvexIntersection):
     @property
     def can_hit_expression(self):
         """Bodies bounded by planes: the ray against a ball around the body (literals of the class)."""
-        ball = plane_body_cull_ball(self.components)
-        if ball is None:
+        if not hasattr(self, '_cull_ball'):
+            self._cull_ball = plane_body_cull_ball(self.components)
+        if self._cull_ball is None:
             return None
-        centre, rho2 = ball
+        centre, rho2 = self._cull_ball
         where = 'local_pos' if numpy.linalg.norm(centre) < 1e-12 else 'local_pos - %s' % vec_literal(centre)
         return '(within || clr_ball_may_be_hit(%s, local_ray, %s, isec_dist))' % (where, float_literal(rho2))
 
