@@ -357,6 +357,32 @@ def test_bench_workload_at_1080p_bit_exact_on_a_subsample(name, rng_mode):
     assert np.array_equal(bits(img[pixels]), bits(oimg))
 
 
+@pytest.mark.parametrize('name,rng_mode', [('scene-dev', 'tape'), ('scene-three-objects', 'tape'),
+                                           ('scene-dev-spectral', 'tape'), ('scene-dev', 'philox')])
+def test_headline_workload_every_pixel_equals_the_oracle(name, rng_mode):
+    """BASELINE's headline workload exactly as bench.py's default step runs it - scene-dev,
+    1920 x 1080, one step of 32 passes in the automatic launch pattern, broadcast tape - on ALL
+    2 073 600 pixels: the sums equal the oracle's bit for bit (66 M samples, a few seconds of the
+    oracle on the box's CPUs), and so do first-hit ids, distances and normals of the whole frame.
+    The same for C2, the spectral variant and the per-pixel random numbers."""
+    from oracle import oracle
+    r = Renderer(load_scene(name, (1920, 1080)), seed=11, overlap_parts='auto', steps_in_flight='auto',
+                 rng_mode=rng_mode)
+    assert r.n_pixels == 2073600 and r.speculate
+    tape = r.make_tape(0, 32)
+    r.upload_tape(tape)
+    r.render_resident(0, 32, timed=False)
+    osc = oracle.OracleScene(r)
+    oimg, _, _ = osc.render(tape)
+    img = r.img.get()
+    assert img[:, :3].std() > 0
+    assert np.array_equal(bits(img), bits(oimg))
+    one = tuple(x[:1] if x is not None else None for x in tape)
+    ids, t, normal = r.first_hit(one)
+    oids, ot, onormal = osc.first_hit(one)
+    assert np.array_equal(ids, oids) and np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(normal), bits(onormal))
+
+
 def test_4k_ray_marching_workload_matches_oracle():
     """BASELINE config C5 at its real size (scene-marchers, 3840 x 2160, 16 passes per launch as
     bench.py runs it): object ids of all 8.3 M primary rays equal the oracle's, distances within
