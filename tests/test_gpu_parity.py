@@ -799,7 +799,8 @@ def test_one_million_triangles_through_the_mesh_reader_against_the_oracle(tmp_pa
     """BASELINE config C4 at its real size, fed the way SURVEY section 8d states it: the generated
     1000 x 500 knot is written as an OFF file, parsed by the native reader (csrc/mesh_io.cpp, the
     counterpart of /root/reference/mesh_formats.py:14-40), filed in the triangle-box tree and rendered
-    at 1920 x 1080 as bench.py does (pass-split program, two steps in flight).  On every 257th ray the
+    at 1920 x 1080 as bench.py does (pass-split program, two steps in flight).  On every 257th ray, and
+    then on every ray of the frame, the
     first-hit ids, distances and normals and the sums of two 2-pass steps equal, bit for bit, what
     the oracle finds walking the reference's own tree (bounding-sphere rule) in the reference's
     stream layout (/root/reference/cl_templates/objects/Octree.cl:32-168)."""
@@ -831,6 +832,11 @@ def test_one_million_triangles_through_the_mesh_reader_against_the_oracle(tmp_pa
     img = r.img.get()
     assert np.isfinite(img).all() and img[:, :3].mean() > 0
     assert np.array_equal(bits(img[pixels]), bits(oimg))
+    # ... and the whole frame: first hits of all 2 073 600 rays and the sums of the four passes
+    oids, ot, onormal = osc.first_hit(one)
+    assert np.array_equal(ids, oids) and np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(normal), bits(onormal))
+    oimg, _, _ = osc.render(tape)
+    assert np.array_equal(bits(img), bits(oimg))
 
 
 def test_several_light_points_per_segment():
