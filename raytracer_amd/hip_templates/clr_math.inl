@@ -40,12 +40,15 @@ CLR_MATH_FN float clr_expf(float x) {
 }
 
 CLR_MATH_FN float clr_logf(float x) {
-    if (!(x == x)) return x;
-    if (x < 0.0f) return clr_bits_to_float(0x7fc00000);
-    if (x == 0.0f) return clr_bits_to_float((int)0xff800000);
-    if (x == clr_bits_to_float(0x7f800000)) return x;
     int e = 0;
-    if (x < 1.17549435e-38f) { x = x * 8388608.0f; e = -23; }   /* subnormal input */
+    if (!(x >= 1.17549435e-38f && x < clr_bits_to_float(0x7f800000))) {   /* one test on the usual way */
+        if (!(x == x)) return x;
+        if (x < 0.0f) return clr_bits_to_float(0x7fc00000);
+        if (x == 0.0f) return clr_bits_to_float((int)0xff800000);
+        if (x == clr_bits_to_float(0x7f800000)) return x;
+        x = x * 8388608.0f;                                    /* subnormal input */
+        e = -23;
+    }
     int bits = clr_float_to_bits(x);
     /* mantissa m in [sqrt(1/2), sqrt(2)) */
     bits += 0x3f800000 - 0x3f3504f3;

@@ -39,6 +39,12 @@ def test_log(lib):
     assert ulp_error(sweep(lib.orc_math_log, xs), np.log(xs.astype(np.float64)))[xs != 1.0].max() < 1.2
     assert lib.orc_math_log(1.0) == 0.0
     assert np.isinf(lib.orc_math_log(0.0)) and np.isnan(lib.orc_math_log(-1.0))
+    # the special cases behind the one range test: zeros, negative numbers, infinities, NaN, subnormals
+    assert lib.orc_math_log(0.0) < 0 and lib.orc_math_log(-0.0) < 0 and np.isinf(lib.orc_math_log(-0.0))
+    assert np.isnan(lib.orc_math_log(float('nan'))) and np.isnan(lib.orc_math_log(float('-inf')))
+    assert lib.orc_math_log(float('inf')) == float('inf')
+    tiny = np.float32([1e-45, 3e-42, 1.1e-38, 1.17549421e-38, 1.17549435e-38, 3.4028235e38])
+    assert ulp_error(sweep(lib.orc_math_log, tiny), np.log(tiny.astype(np.float64))).max() < 1.2
 
 
 def test_tan(lib):
