@@ -144,6 +144,10 @@ def start_process_group(local_rank):
     with ONE GPU (development, tests/test_gpu_cli.py): CLRAY_DIST_BACKEND=gloo lets several workers
     share GPU 0 (CLRAY_ONE_GPU=1); the exchange step then goes through host memory (Shard.combine).
     Returns (torch.distributed, device index of this worker)."""
+    # RCCL shares device memory between the workers through dmabuf handles; the legacy IPC mode of
+    # the HSA runtime fails there (hipIpcGetMemHandle: invalid argument).  Read when the runtime
+    # starts, i.e. at this worker's first HIP call below; an explicit setting is left alone.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
     import torch.distributed as dist
     backend = os.environ.get('CLRAY_DIST_BACKEND', 'nccl')
