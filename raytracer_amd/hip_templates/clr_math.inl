@@ -16,9 +16,11 @@ CLR_MATH_FN float clr_bits_to_float(int i) { float f; __builtin_memcpy(&f, &i, 4
 CLR_MATH_FN int clr_float_to_bits(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 
 CLR_MATH_FN float clr_expf(float x) {
-    if (!(x == x)) return x;                               /* NaN */
-    if (x > 88.7228394f) return clr_bits_to_float(0x7f800000);
-    if (x < -103.972084f) return 0.0f;
+    if (!(x >= -103.972084f && x <= 88.7228394f)) {        /* one test on the usual way */
+        if (!(x == x)) return x;                           /* NaN */
+        if (x > 88.7228394f) return clr_bits_to_float(0x7f800000);
+        return 0.0f;                                       /* x < -103.972084 */
+    }
     const float k = __builtin_rintf(x * 1.44269502f);
     /* r = x - k ln2, ln2 split so that k * hi is exact */
     const float r = (x - k * 0.693145752f) - k * 1.42860677e-06f;

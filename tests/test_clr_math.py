@@ -32,6 +32,11 @@ def test_exp(lib):
     assert ulp_error(sweep(lib.orc_math_exp, xs), np.exp(xs.astype(np.float64))).max() < 1.5
     assert lib.orc_math_exp(0.0) == 1.0 and lib.orc_math_exp(-0.0) == 1.0     # exp(-0*d) must be 1
     assert lib.orc_math_exp(-1000.0) == 0.0 and np.isinf(lib.orc_math_exp(100.0))
+    # the special cases behind the one range test, and both of its ends
+    assert np.isnan(lib.orc_math_exp(float('nan'))) and lib.orc_math_exp(float('-inf')) == 0.0
+    assert lib.orc_math_exp(float('inf')) == float('inf')
+    assert lib.orc_math_exp(np.float32(88.7228394)) > 3.0e38 and np.isinf(lib.orc_math_exp(np.float32(88.72284)))
+    assert 0.0 < lib.orc_math_exp(np.float32(-103.0)) < 3e-45 and lib.orc_math_exp(np.float32(-103.9721)) == 0.0
 
 
 def test_log(lib):
