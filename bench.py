@@ -243,7 +243,7 @@ def main():
     if args.regenerate is not None:
         r.regenerate = bool(args.regenerate)
     if args.occupancy_hint == 'auto':
-        r.tune_occupancy()                      # part of the program build, outside the timed region
+        r.tune_occupancy(passes=args.passes_per_step)      # part of the program build, outside the timed region
         if rank == 0:
             print('occupancy tuning (ms per hint):', {str(k): round(v, 3) for k, v in r.occupancy_timings.items()},
                   'spilled vector registers:', r.occupancy_scratch, file=sys.stderr)

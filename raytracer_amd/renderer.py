@@ -519,7 +519,7 @@ class Renderer:
             acc.set_global('clr_material_colors', self.material_colors)
             acc.set_global('clr_material_scalars', self.material_scalars)
 
-    def tune_occupancy(self, candidates=(None, 4, 5, 6, 7, 8), passes=16, rounds=7, verbose=False):
+    def tune_occupancy(self, candidates=(None, 4, 5, 6, 7, 8), passes=16, rounds=None, verbose=False):
         """Pick the occupancy hint of the render kernel (second __launch_bounds__ argument) by
         timing: the register allocation of these scene-specialised kernels lands on either side
         of a waves-per-SIMD boundary more or less by chance, and one more resident wave or a few
@@ -546,9 +546,13 @@ class Renderer:
             self._build(keep_previous=True)
             built[hint] = (self.acc.prog, code)
             meta[hint] = self.acc.last_metadata.get('clr_render', {})
-            self.render_tape(tape)                                       # warm-up
+            warm_ms = self.render_tape(tape)[0]                          # warm-up
         self.acc.drop_program(previous)
         samples = {hint: [] for hint in candidates}
+        if rounds is None:
+            # candidates often lie within 2-3 % of each other, the spread of single launches:
+            # about 0.3 s of launches per candidate, 7 to 31 rounds (medians decide)
+            rounds = int(min(31, max(7, 300.0 / max(warm_ms, 1e-3))))
         for _ in range(rounds):
             for hint in candidates:
                 self.acc.use_program(built[hint][0])
