@@ -124,7 +124,10 @@ class Octree(Tracer):
         work on the leaves of the others (same tests, same results).
         overlap (native builder): 'reference' = the reference's bounding-sphere rule for filing a
         face under a node (objects/octree.py:201-233), 'sat' = the triangle against the node's box:
-        same hits, a fraction of the leaf records (for large meshes)."""
+        same hits, a fraction of the leaf records (for large meshes).
+        ropes / two_level (pooled traversal only): how the next leaf is found - through a table of
+        neighbour links (measured slower, off), or with node records that take the descent down two
+        levels per memory access (default with pooled tests); same leaves, same hits either way."""
         if overlap not in ('reference', 'sat'):
             raise ValueError("overlap must be 'reference' or 'sat'")
         if overlap != 'reference' and builder == 'python' and layout != 'flat':
