@@ -319,6 +319,11 @@ def test_occupancy_choice_avoids_builds_that_spill_for_noise_level_gains():
     assert pick_occupancy_hint(timings, scratch) == 7
     # no difference in scratch: plain minimum
     assert pick_occupancy_hint({None: 2.0, 5: 1.5}, {None: 0, 5: 0}) == 5
+    # a few spilled registers: the margin grows with their number (0.4 % each, at most 3 %)
+    assert pick_occupancy_hint({None: 1.464, 7: 1.464, 8: 1.447}, {None: 0, 7: 0, 8: 2}) == 8
+    assert pick_occupancy_hint({None: 1.464, 7: 1.464, 8: 1.458}, {None: 0, 7: 0, 8: 2}) in (None, 7)
+    assert pick_occupancy_hint({None: 2.0, 6: 1.96}, {None: 0, 6: 40}) is None
+    assert pick_occupancy_hint({None: 2.0, 6: 1.90}, {None: 0, 6: 40}) == 6
 
 
 def test_pass_split_launches_are_cut_to_bound_the_addend_log():
