@@ -246,7 +246,8 @@ def main():
         r.tune_occupancy(passes=args.passes_per_step)      # part of the program build, outside the timed region
         if rank == 0:
             print('occupancy tuning (ms per hint):', {str(k): round(v, 3) for k, v in r.occupancy_timings.items()},
-                  'spilled vector registers:', r.occupancy_scratch, file=sys.stderr)
+                  'spilled vector registers:', r.occupancy_scratch,
+                  'launch chains (ms per step):', getattr(r, 'chain_timings', None), file=sys.stderr)
     frame = torch.zeros((shard.frame_rows, 4), dtype=torch.float32, device='cuda')
     img = shard.my_rows(frame)[:r.n_pixels]
     r.use_image_buffer(img.data_ptr())
@@ -302,6 +303,7 @@ def main():
     # Roofline leg, outside the timed region: whole-frame launches, one at a time, each between a HIP
     # event pair of its own on the stream it is launched on; for a pass-split program the time of
     # clr_render alone (clr_last_split_ms).  This is the duration rocprofv3's kernel trace reports.
+    launches_per_step, steps_in_flight = len(r.part_bounds()) - 1, (r.steps_in_flight if r.split_passes else 1)
     lone_ms, n_lone = None, 0
     if rank == 0 and world == 1:
         r.overlap_parts, r.steps_in_flight = 1, 1
@@ -329,8 +331,8 @@ def main():
                    'passes_per_step': P, 'pixels': r.n_pixels,
                    'speculative_exact_arithmetic': bool(r.speculate),
                    'occupancy_hint': r.min_waves_per_simd,
-                   'launches_per_step': len(r.part_bounds()) - 1,
-                   'steps_in_flight': r.steps_in_flight if r.split_passes else 1,
+                   'launches_per_step': launches_per_step,
+                   'steps_in_flight': steps_in_flight,
                    'kernel_registers': {key.lstrip('.'): value for key, value in getattr(r, 'kernel_metadata', {}).items()
                                         if key in ('.vgpr_count', '.sgpr_count', '.vgpr_spill_count',
                                                    '.sgpr_spill_count', '.private_segment_fixed_size',

@@ -591,6 +591,23 @@ class Renderer:
         for hint, (prog, _) in built.items():
             if hint != best:
                 self.acc.drop_program(prog)
+        # one-lane programs with the automatic launch pattern: two launch chains or three, by the
+        # same timing (scene-dev at eight waves: three are 1 % faster; a third chain has to win by 0.5 %)
+        if self._overlap_parts == 'auto' and not self.split_passes and self.n_pixels >= 3 * 4096 and rounds > 1:
+            parts = {}
+            for k in (2, 3):
+                self._auto_parts = k
+                sample()
+            for _ in range(rounds):
+                for k in (2, 3):
+                    self._auto_parts = k
+                    parts.setdefault(k, []).append(sample())
+            medians = {k: float(np.median(v)) for k, v in parts.items()}
+            self._auto_parts = 3 if medians[3] < 0.995 * medians[2] else 2
+            self.chain_timings = medians
+            if verbose:
+                print('launch chains, median ms per step:', medians)
+        self.acc.finish()
         self.img = saved_img
         self.dev_pass_tape, self.dev_bounce_tape, self.dev_rows, self._tape_capacity, self._resident_passes = saved_tape
         self._resident_first_pass = saved_first
@@ -704,7 +721,8 @@ class Renderer:
     @property
     def overlap_parts(self):
         if self._overlap_parts == 'auto':
-            return 1 if self.split_passes else 2
+            # (tune_occupancy may have timed two chains against three: _auto_parts)
+            return 1 if self.split_passes else getattr(self, '_auto_parts', 2)
         return max(1, int(self._overlap_parts))
 
     @overlap_parts.setter
