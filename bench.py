@@ -247,7 +247,8 @@ def main():
         if rank == 0:
             print('occupancy tuning (ms per hint):', {str(k): round(v, 3) for k, v in r.occupancy_timings.items()},
                   'spilled vector registers:', r.occupancy_scratch,
-                  'launch chains (ms per step):', getattr(r, 'chain_timings', None), file=sys.stderr)
+                  'launch chains (ms per step):', getattr(r, 'chain_timings', None),
+                  'steps in flight (ms per step):', getattr(r, 'flight_timings', None), file=sys.stderr)
     frame = torch.zeros((shard.frame_rows, 4), dtype=torch.float32, device='cuda')
     img = shard.my_rows(frame)[:r.n_pixels]
     r.use_image_buffer(img.data_ptr())

@@ -607,6 +607,32 @@ class Renderer:
             self.chain_timings = medians
             if verbose:
                 print('launch chains, median ms per step:', medians)
+        # pass-split programs with the automatic launch pattern: two steps in flight or three (each
+        # with an addend log of its own), timed over twice as many steps so that three can overlap;
+        # the launch counter restarts with the pattern (a step's sums are added after those of the
+        # step before it, found by its slot)
+        if self._steps_in_flight == 'auto' and self.split_passes and rounds > 1:
+            flights = {}
+
+            def sample_flight(k):
+                self.acc.finish()
+                self._auto_in_flight, self._launch_counter = k, 0
+                self.acc.timer_begin()
+                for _ in range(2 * TUNE_STEPS):
+                    self.render_resident(0, passes, timed=False)
+                self.join_parts()
+                return self.acc.timer_end() / (2 * TUNE_STEPS)
+            for k in (2, 3):
+                sample_flight(k)
+            for _ in range(rounds):
+                for k in (2, 3):
+                    flights.setdefault(k, []).append(sample_flight(k))
+            medians = {k: float(np.median(v)) for k, v in flights.items()}
+            self.acc.finish()
+            self._auto_in_flight, self._launch_counter = (3 if medians[3] < 0.98 * medians[2] else 2), 0
+            self.flight_timings = medians
+            if verbose:
+                print('steps in flight, median ms per step:', medians)
         self.acc.finish()
         self.img = saved_img
         self.dev_pass_tape, self.dev_bounce_tape, self.dev_rows, self._tape_capacity, self._resident_passes = saved_tape
@@ -732,7 +758,8 @@ class Renderer:
     @property
     def steps_in_flight(self):
         if self._steps_in_flight == 'auto':
-            return 2 if self.split_passes else 1
+            # (tune_occupancy may have timed two steps in flight against three: _auto_in_flight)
+            return getattr(self, '_auto_in_flight', 2) if self.split_passes else 1
         return max(1, int(self._steps_in_flight))
 
     @steps_in_flight.setter
