@@ -557,20 +557,24 @@ class Renderer:
             warm_ms = self.render_tape(tape)[0]                          # warm-up
         self.acc.drop_program(previous)
         samples = {hint: [] for hint in candidates}
+        # launches that take a quarter of a second or more: one step per sample, three rounds, and
+        # the launch pattern stays as it is (the tuning should not take minutes)
+        heavy = warm_ms >= 250.0
+        steps = 1 if heavy else TUNE_STEPS
         if rounds is None:
             # candidates often lie within 2-3 % of each other, the spread of single launches:
             # about 0.3 s of launches per candidate, 7 to 31 rounds (medians decide)
-            rounds = int(min(31, max(7, 300.0 / max(TUNE_STEPS * warm_ms, 1e-3))))
+            rounds = 3 if heavy else int(min(31, max(7, 300.0 / max(steps * warm_ms, 1e-3))))
 
         def sample():
-            # TUNE_STEPS steps back to back in the launch pattern that will be used (launch chains
+            # `steps` steps back to back in the launch pattern that will be used (launch chains
             # on slices, steps in flight): what one more wave or a few spills are worth shows
             # there, where the launches overlap, more than in a launch that runs alone
             self.acc.timer_begin()
-            for _ in range(TUNE_STEPS):
+            for _ in range(steps):
                 self.render_resident(0, passes, timed=False)
             self.join_parts()
-            return self.acc.timer_end() / TUNE_STEPS
+            return self.acc.timer_end() / steps
         for _ in range(rounds):
             for hint in candidates:
                 self.acc.use_program(built[hint][0])
@@ -593,7 +597,7 @@ class Renderer:
                 self.acc.drop_program(prog)
         # one-lane programs with the automatic launch pattern: two launch chains or three, by the
         # same timing (scene-dev at eight waves: three are 1 % faster; a third chain has to win by 0.5 %)
-        if self._overlap_parts == 'auto' and not self.split_passes and self.n_pixels >= 3 * 4096 and rounds > 1:
+        if self._overlap_parts == 'auto' and not self.split_passes and self.n_pixels >= 3 * 4096 and rounds > 1 and not heavy:
             parts = {}
             for k in (2, 3):
                 self._auto_parts = k
@@ -611,7 +615,7 @@ class Renderer:
         # with an addend log of its own), timed over twice as many steps so that three can overlap;
         # the launch counter restarts with the pattern (a step's sums are added after those of the
         # step before it, found by its slot)
-        if self._steps_in_flight == 'auto' and self.split_passes and rounds > 1:
+        if self._steps_in_flight == 'auto' and self.split_passes and rounds > 1 and not heavy:
             flights = {}
 
             def sample_flight(k):
