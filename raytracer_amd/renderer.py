@@ -581,10 +581,10 @@ class Renderer:
                 samples[hint].append(sample())
         timings = {hint: float(np.median(v)) for hint, v in samples.items()}
         # vector registers each build spills to scratch memory (code object metadata): a build that
-        # spills more than the leanest one moves registers through HBM inside the segment loop (as
-        # measured on scene-dev with hint 7: 7 x the algorithmic HBM writes), which hurts any
-        # neighbour on the GPU and is bought by noise-level gains; such a build has to win by
-        # SPILL_MARGIN to be chosen
+        # spills more than the leanest one moves registers through HBM inside the segment loop (a
+        # round-2 build of scene-dev with dozens of them: 7 x the algorithmic HBM writes), which
+        # hurts any neighbour on the GPU; such a build has to win by a margin that grows with the
+        # number of registers it spills (pick_occupancy_hint)
         scratch = {hint: int(meta[hint].get('.vgpr_spill_count', 0)) for hint in candidates}
         if verbose:
             print('occupancy hints, median ms:', timings, 'spilled vector registers:', scratch)
